@@ -1,0 +1,124 @@
+/*
+ * makani_amd.h -- C ABI of the MI355X-native SFNO spectral hot path.
+ *
+ * One shared library (libmakani_amd.so, built by hipcc for gfx950) exports the
+ * entry points below.  Plain pointers and sizes only; every device pointer is a
+ * HIP device address, every `stream` is a hipStream_t passed as void*.  All
+ * kernels are launched asynchronously on `stream` (graph-capturable: no
+ * allocation, no host synchronisation inside).  Return value: 0 on success,
+ * non-zero on error (mk_last_error() holds the message for the calling thread).
+ *
+ * The reference (choutilin/makani) has no FFI: its hot path is PyTorch ops
+ * behind nn.Module interfaces.  Each entry point names the reference call it
+ * replaces (file:line under the reference tree); INTEGRATION.md shows the
+ * ctypes binding a maintainer would add.
+ *
+ * Private device layouts (chosen for coalesced HBM access on CDNA4):
+ *   grid field   x  [BC][K][N]      real fp32, N contiguous      (= NCHW, B*C flattened)
+ *   Fourier rows xf [M][K][BC]      complex64 interleaved, BC contiguous ("MKBC")
+ *   spectrum     c  [L][M][BC]      complex64 interleaved, BC contiguous ("LMBC")
+ *   dhconv weight w [L][I][O]       complex64 interleaved, O contiguous
+ *   Legendre tab    [M][L][KP]      fp32, KP = K rounded up to 32, zero padded
+ * The public torch layout [B,C,L,M] complex64 is converted with mk_spec_pack /
+ * mk_spec_unpack.
+ */
+#ifndef MAKANI_AMD_H
+#define MAKANI_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- library ---------------------------------------------------------- */
+int mk_version(void);
+const char* mk_last_error(void);
+
+/* ---- host-side precompute (float64 arithmetic, no GPU needed) ---------- */
+/* grid: 0 = "equiangular" (Clenshaw-Curtis), 1 = "legendre-gauss". */
+
+/* Colatitudes (ascending from the north pole) and quadrature weights, nlat each.
+ * Replaces torch_harmonics.quadrature.{clenshaw_curtiss,legendre_gauss}_weights
+ * (reference call sites: makani/utils/grids.py:19,32,77,83; sfnonet.py:536-539). */
+int mk_quadrature(int grid, int nlat, double* theta, double* weights);
+
+/* Padded row length of the Legendre table for nlat latitudes. */
+int mk_legendre_kpad(int nlat);
+
+/* Orthonormal associated Legendre table with Condon-Shortley phase,
+ * out[m][l][k] for m<mmax, l<lmax, k<kpad (zero for k>=nlat and l<m), fp32
+ * rounded from float64.  with_quad_weights != 0 multiplies by w_k (forward
+ * transform table, torch-harmonics RealSHT.weights); 0 gives the synthesis
+ * table (InverseRealSHT.pct).  Replaces torch_harmonics.legendre._precompute_legpoly
+ * as invoked by sfnonet.py:536-539. */
+int mk_legendre_table(int grid, int nlat, int lmax, int mmax, int with_quad_weights, float* out);
+
+/* Twiddle table for real FFTs of length nlon: out holds 2*(nlon/2) + 2*(nlon/2+1)
+ * floats: exp(-2 pi i j/(nlon/2)) for j<nlon/2, then exp(-2 pi i m/nlon) for m<=nlon/2. */
+int mk_fft_twiddle_len(int nlon);
+int mk_fft_twiddles(int nlon, float* out);
+
+/* ---- longitudinal real FFT (K1 / K4) ----------------------------------- */
+/* xf[m][k][bc] = s_m * sum_n x[bc][k][n] exp(-2 pi i m n / nlon), m < mmax, with
+ * s_0 = scale0, s_{nlon/2} = scale_h (Nyquist), s_m = scale_m otherwise.
+ * Forward SHT uses all three = 2 pi / nlon:
+ * `2*pi*torch.fft.rfft(x, dim=-1, norm="forward")[..., :mmax]` of torch-harmonics
+ * RealSHT.forward (called at spectral_convolution.py:131, sfnonet.py:596).
+ * With (1, 2, 1) it is the adjoint of mk_irfft(1, 1, 1) (backward of K4).
+ * x_dtype: 0 = fp32, 1 = bf16 input rows. */
+int mk_rfft(const void* x, int x_dtype, float* xf, const float* twiddles,
+            int bc, int nlat, int nlon, int mmax, float scale0, float scale_m, float scale_h,
+            void* stream);
+
+/* x[bc][k][n] = s_0 Re(xf[0][k][bc]) + sum_{0<m<mmax, m != nlon/2} 2 s_m Re(xf[m][k][bc] exp(2 pi i m n/nlon))
+ *               + s_h Re(xf[nlon/2][k][bc]) (-1)^n   (only if mmax == nlon/2+1).
+ * (1, 1, 1) is `torch.fft.irfft(x, n=nlon, dim=-1, norm="forward")` of
+ * InverseRealSHT.forward (spectral_convolution.py:133,141; sfnonet.py:598): modes
+ * >= mmax are zero, imaginary parts of the zero and Nyquist modes are ignored.
+ * With (2 pi/nlon, pi/nlon, 2 pi/nlon) it is the adjoint of mk_rfft (backward of K1). */
+int mk_irfft(const float* xf, float* x, const float* twiddles,
+             int bc, int nlat, int nlon, int mmax, float scale0, float scale_m, float scale_h,
+             void* stream);
+
+/* ---- Legendre contraction on fp32 MFMA (K2 / K3) ------------------------ */
+/* Analysis: c[l][m][n] = sum_k tab[m_off+m][l_off.. l][k] xf[m][k][n], n < 2*bc (re/im as
+ * independent real columns), only l >= m (global indices); entries with l < m are not
+ * written.  torch-harmonics `einsum('...kmr,mlk->...lmr', x, weights)`.
+ * m_off: global index of local mode 0 (w-sharded tables); tab points at the
+ * full [mmax_glob][lmax][kpad] table. */
+int mk_legendre_fwd(const float* xf, const float* tab, float* c,
+                    int bc, int nlat, int lmax, int mmax_loc, int m_off, int mmax_glob, void* stream);
+
+/* Synthesis: xf[m][k][n] = sum_{l>=m} tab[m][l][k] c[l][m][n].
+ * torch-harmonics `einsum('...lmr,mlk->...kmr', x, pct)`.  Also the backward of
+ * mk_legendre_fwd (with the analysis table); mk_legendre_fwd with the synthesis
+ * table is the backward of this one. */
+int mk_legendre_inv(const float* c, const float* tab, float* xf,
+                    int bc, int nlat, int lmax, int mmax_loc, int m_off, int mmax_glob, void* stream);
+
+/* ---- spectral filter contraction (K5) ---------------------------------- */
+/* y[l][m][b][o] = sum_i x[l][m][b][i] * w[l][i][o]  (complex), for global m <= l.
+ * Replaces _contract_dhconv `einsum("bixy,iox->boxy")` (contractions.py:130-136,
+ * dispatched by factorizations.py:167-200, called at spectral_convolution.py:137).
+ * l_off / m_off: global indices of local l = 0 / m = 0 (h / w sharding). */
+int mk_dhconv_fwd(const float* x, const float* w, float* y, int lloc, int mloc, int batch,
+                  int cin, int cout, int l_off, int m_off, void* stream);
+/* gx[l][m][b][i] = sum_o gy[l][m][b][o] * conj(w[l][i][o]) */
+int mk_dhconv_dgrad(const float* gy, const float* w, float* gx, int lloc, int mloc, int batch,
+                    int cin, int cout, int l_off, int m_off, void* stream);
+/* gw[l][i][o] = sum_{m<=l, b} conj(x[l][m][b][i]) * gy[l][m][b][o] */
+int mk_dhconv_wgrad(const float* x, const float* gy, float* gw, int lloc, int mloc, int batch,
+                    int cin, int cout, int l_off, int m_off, void* stream);
+
+/* ---- layout conversion -------------------------------------------------- */
+/* torch [BC][L][M] complex64  <->  private [L][M][BC] complex64.  unpack writes
+ * exact zeros where global l < m (what the reference's zero table entries give). */
+int mk_spec_pack(const float* c_std, float* c_prv, int bc, int lloc, int mloc, void* stream);
+int mk_spec_unpack(const float* c_prv, float* c_std, int bc, int lloc, int mloc,
+                   int l_off, int m_off, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAKANI_AMD_H */

@@ -1,0 +1,65 @@
+"""ctypes binding of libmakani_amd.so -- the C ABI declared in include/makani_amd.h.
+
+The library is the product; there is no fallback.  If it is missing (and cannot be
+built because hipcc is absent) importing any compute entry point raises.
+"""
+import ctypes
+import os
+
+from . import build as _build
+
+_LIB = None
+
+_c_int = ctypes.c_int
+_c_float = ctypes.c_float
+_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/makani_amd.h
+SIGNATURES = {
+    "mk_version": (_c_int, []),
+    "mk_last_error": (ctypes.c_char_p, []),
+    "mk_quadrature": (_c_int, [_c_int, _c_int, _vp, _vp]),
+    "mk_legendre_kpad": (_c_int, [_c_int]),
+    "mk_legendre_table": (_c_int, [_c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_fft_twiddle_len": (_c_int, [_c_int]),
+    "mk_fft_twiddles": (_c_int, [_c_int, _vp]),
+    "mk_rfft": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _vp]),
+    "mk_irfft": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _vp]),
+    "mk_legendre_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_legendre_inv": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_dhconv_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_dhconv_dgrad": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_dhconv_wgrad": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_spec_pack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp]),
+    "mk_spec_unpack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+}
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load (building first if the sources are newer) and return the ctypes handle."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = _build.LIB
+    if not os.path.exists(path):
+        path = _build.build(verbose=False)
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:  # pragma: no cover - environment problem, never silent
+        raise RuntimeError(f"makani_amd: cannot load the HIP extension {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().mk_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"makani_amd {what} failed (code {rc}): {msg}")

@@ -1,0 +1,325 @@
+"""Autograd operators over the C ABI (include/makani_amd.h).
+
+Tensors cross the boundary as raw device pointers + sizes; torch is only the
+allocator and the stream owner.  Every launch goes to torch's *current* HIP
+stream, so the ops are capturable in a HIP graph exactly like the reference's
+step is captured in ``makani/utils/trainer.py:84-152``.
+
+Private layouts (see the header): ``xf`` = complex64 ``[M, K, BC]``, spectrum =
+complex64 ``[L, M, BC]`` (channels last), dhconv weight = complex64 ``[L, I, O]``.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+GRIDS = {"equiangular": 0, "legendre-gauss": 1}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _need_cuda(*tensors):
+    for t in tensors:
+        if not t.is_cuda:
+            raise RuntimeError("makani_amd: the spectral ops run only on a HIP device (got a CPU tensor); "
+                               "there is no CPU fallback")
+
+
+# ----------------------------------------------------------------------------
+# host-side precompute (float64 in C, no GPU needed)
+# ----------------------------------------------------------------------------
+def quadrature(grid, nlat):
+    """(colatitudes ascending from the north pole, quadrature weights) as float64 numpy."""
+    if grid not in GRIDS:
+        raise ValueError(f"Unknown quadrature mode {grid}")
+    lib = _lib.load()
+    theta = np.empty(nlat, dtype=np.float64)
+    w = np.empty(nlat, dtype=np.float64)
+    _lib.check(lib.mk_quadrature(GRIDS[grid], nlat, theta.ctypes.data, w.ctypes.data), "mk_quadrature")
+    return theta, w
+
+
+def legendre_kpad(nlat):
+    return _lib.load().mk_legendre_kpad(nlat)
+
+
+def legendre_table(grid, nlat, lmax, mmax, with_quad_weights):
+    """fp32 table [mmax, lmax, kpad] (zero padded along k) as a CPU torch tensor."""
+    if grid not in GRIDS:
+        raise ValueError(f"Unknown quadrature mode {grid}")
+    lib = _lib.load()
+    kp = lib.mk_legendre_kpad(nlat)
+    out = torch.empty(mmax, lmax, kp, dtype=torch.float32)
+    _lib.check(lib.mk_legendre_table(GRIDS[grid], nlat, lmax, mmax, int(bool(with_quad_weights)), out.data_ptr()),
+               "mk_legendre_table")
+    return out
+
+
+def fft_twiddles(nlon):
+    lib = _lib.load()
+    out = torch.empty(lib.mk_fft_twiddle_len(nlon), dtype=torch.float32)
+    _lib.check(lib.mk_fft_twiddles(nlon, out.data_ptr()), "mk_fft_twiddles")
+    return out
+
+
+# ----------------------------------------------------------------------------
+# raw (non-differentiable) launches
+# ----------------------------------------------------------------------------
+def rfft_raw(x, twiddles, mmax, s0, sm, sh):
+    """x real [BC, K, N] (fp32 or bf16) -> xf complex64 [mmax, K, BC]."""
+    _need_cuda(x, twiddles)
+    assert x.dim() == 3 and x.is_contiguous()
+    bc, k, n = x.shape
+    if x.dtype == torch.float32:
+        dt = 0
+    elif x.dtype == torch.bfloat16:
+        dt = 1
+    else:
+        raise TypeError(f"mk_rfft: unsupported dtype {x.dtype}")
+    xf = torch.empty(mmax, k, bc, dtype=torch.complex64, device=x.device)
+    _lib.check(_lib.load().mk_rfft(x.data_ptr(), dt, xf.data_ptr(), twiddles.data_ptr(), bc, k, n, mmax,
+                                   s0, sm, sh, _stream()), "mk_rfft")
+    return xf
+
+
+def irfft_raw(xf, twiddles, nlon, s0, sm, sh):
+    """xf complex64 [M, K, BC] -> x fp32 [BC, K, nlon]."""
+    _need_cuda(xf, twiddles)
+    assert xf.dim() == 3 and xf.is_contiguous() and xf.dtype == torch.complex64
+    m, k, bc = xf.shape
+    x = torch.empty(bc, k, nlon, dtype=torch.float32, device=xf.device)
+    _lib.check(_lib.load().mk_irfft(xf.data_ptr(), x.data_ptr(), twiddles.data_ptr(), bc, k, nlon, m,
+                                    s0, sm, sh, _stream()), "mk_irfft")
+    return x
+
+
+def legendre_fwd_raw(xf, table, lmax, m_off=0):
+    """xf [Mloc, K, BC] -> spectrum [lmax, Mloc, BC]; rows l < m are left unwritten."""
+    _need_cuda(xf, table)
+    assert xf.is_contiguous() and xf.dtype == torch.complex64 and table.dtype == torch.float32
+    mloc, k, bc = xf.shape
+    mg, lt, kp = table.shape
+    assert lt == lmax and kp == legendre_kpad(k), "Legendre table does not match the operand"
+    c = torch.empty(lmax, mloc, bc, dtype=torch.complex64, device=xf.device)
+    _lib.check(_lib.load().mk_legendre_fwd(xf.data_ptr(), table.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
+                                           m_off, mg, _stream()), "mk_legendre_fwd")
+    return c
+
+
+def legendre_inv_raw(c, table, nlat, m_off=0):
+    """spectrum [L, Mloc, BC] -> xf [Mloc, nlat, BC]."""
+    _need_cuda(c, table)
+    assert c.is_contiguous() and c.dtype == torch.complex64 and table.dtype == torch.float32
+    lmax, mloc, bc = c.shape
+    mg, lt, kp = table.shape
+    assert lt == lmax and kp == legendre_kpad(nlat), "Legendre table does not match the operand"
+    xf = torch.empty(mloc, nlat, bc, dtype=torch.complex64, device=c.device)
+    _lib.check(_lib.load().mk_legendre_inv(c.data_ptr(), table.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
+                                           m_off, mg, _stream()), "mk_legendre_inv")
+    return xf
+
+
+def spec_pack_raw(c_std):
+    """[BC, L, M] complex64 -> [L, M, BC]."""
+    _need_cuda(c_std)
+    assert c_std.dim() == 3 and c_std.is_contiguous() and c_std.dtype == torch.complex64
+    bc, l, m = c_std.shape
+    out = torch.empty(l, m, bc, dtype=torch.complex64, device=c_std.device)
+    _lib.check(_lib.load().mk_spec_pack(c_std.data_ptr(), out.data_ptr(), bc, l, m, _stream()), "mk_spec_pack")
+    return out
+
+
+def spec_unpack_raw(c_prv, l_off=0, m_off=0):
+    """[L, M, BC] complex64 -> [BC, L, M], exact zeros where l_off + l < m_off + m."""
+    _need_cuda(c_prv)
+    assert c_prv.dim() == 3 and c_prv.is_contiguous() and c_prv.dtype == torch.complex64
+    l, m, bc = c_prv.shape
+    out = torch.empty(bc, l, m, dtype=torch.complex64, device=c_prv.device)
+    _lib.check(_lib.load().mk_spec_unpack(c_prv.data_ptr(), out.data_ptr(), bc, l, m, l_off, m_off, _stream()),
+               "mk_spec_unpack")
+    return out
+
+
+def _w_phys(w):
+    """Physical [L, I, O] contiguous view/copy of a dhconv weight of logical shape [I, O, L]."""
+    wp = w.permute(2, 0, 1)
+    return wp if wp.is_contiguous() else wp.contiguous()
+
+
+def dhconv_fwd_raw(x, w_phys, batch, l_off=0, m_off=0):
+    _need_cuda(x, w_phys)
+    assert x.is_contiguous() and x.dtype == torch.complex64 and w_phys.is_contiguous() and w_phys.dtype == torch.complex64
+    lloc, mloc, bc = x.shape
+    l2, cin, cout = w_phys.shape
+    assert l2 == lloc and bc == batch * cin, "dhconv operand shapes do not match"
+    y = torch.empty(lloc, mloc, batch * cout, dtype=torch.complex64, device=x.device)
+    _lib.check(_lib.load().mk_dhconv_fwd(x.data_ptr(), w_phys.data_ptr(), y.data_ptr(), lloc, mloc, batch, cin, cout,
+                                         l_off, m_off, _stream()), "mk_dhconv_fwd")
+    return y
+
+
+def dhconv_dgrad_raw(gy, w_phys, batch, l_off=0, m_off=0):
+    _need_cuda(gy, w_phys)
+    assert gy.is_contiguous() and gy.dtype == torch.complex64 and w_phys.is_contiguous()
+    lloc, mloc, bo = gy.shape
+    l2, cin, cout = w_phys.shape
+    assert l2 == lloc and bo == batch * cout
+    gx = torch.empty(lloc, mloc, batch * cin, dtype=torch.complex64, device=gy.device)
+    _lib.check(_lib.load().mk_dhconv_dgrad(gy.data_ptr(), w_phys.data_ptr(), gx.data_ptr(), lloc, mloc, batch, cin,
+                                           cout, l_off, m_off, _stream()), "mk_dhconv_dgrad")
+    return gx
+
+
+def dhconv_wgrad_raw(x, gy, batch, l_off=0, m_off=0):
+    _need_cuda(x, gy)
+    assert x.is_contiguous() and gy.is_contiguous() and x.dtype == torch.complex64 and gy.dtype == torch.complex64
+    lloc, mloc, bi = x.shape
+    cin, cout = bi // batch, gy.shape[2] // batch
+    gw = torch.empty(lloc, cin, cout, dtype=torch.complex64, device=x.device)
+    _lib.check(_lib.load().mk_dhconv_wgrad(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), lloc, mloc, batch, cin, cout,
+                                           l_off, m_off, _stream()), "mk_dhconv_wgrad")
+    return gw
+
+
+# ----------------------------------------------------------------------------
+# differentiable operators (all linear in the data: backward = adjoint launch)
+# ----------------------------------------------------------------------------
+class _RFFT(torch.autograd.Function):
+    """x [BC, K, N] -> xf [mmax, K, BC] = 2 pi rfft(x, norm="forward")[..., :mmax] (K1)."""
+
+    @staticmethod
+    def forward(ctx, x, twiddles, mmax):
+        ctx.save_for_backward(twiddles)
+        ctx.nlon = x.shape[-1]
+        ctx.in_dtype = x.dtype
+        s = 2.0 * math.pi / ctx.nlon
+        return rfft_raw(x, twiddles, mmax, s, s, s)
+
+    @staticmethod
+    def backward(ctx, gxf):
+        (tw,) = ctx.saved_tensors
+        n = ctx.nlon
+        gx = irfft_raw(gxf.contiguous(), tw, n, 2.0 * math.pi / n, math.pi / n, 2.0 * math.pi / n)
+        return gx.to(ctx.in_dtype), None, None
+
+
+class _IRFFT(torch.autograd.Function):
+    """xf [M, K, BC] -> x [BC, K, nlon] = irfft(xf, n=nlon, norm="forward") (K4)."""
+
+    @staticmethod
+    def forward(ctx, xf, twiddles, nlon):
+        ctx.save_for_backward(twiddles)
+        ctx.mmax = xf.shape[0]
+        return irfft_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0)
+
+    @staticmethod
+    def backward(ctx, gx):
+        (tw,) = ctx.saved_tensors
+        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0), None, None
+
+
+class _LegendreFwd(torch.autograd.Function):
+    """xf [Mloc, K, BC] -> c [L, Mloc, BC] with table[m_off + m] (K2)."""
+
+    @staticmethod
+    def forward(ctx, xf, table, lmax, m_off):
+        ctx.save_for_backward(table)
+        ctx.nlat, ctx.m_off = xf.shape[1], m_off
+        return legendre_fwd_raw(xf, table, lmax, m_off)
+
+    @staticmethod
+    def backward(ctx, gc):
+        (table,) = ctx.saved_tensors
+        return legendre_inv_raw(gc.contiguous(), table, ctx.nlat, ctx.m_off), None, None, None
+
+
+class _LegendreInv(torch.autograd.Function):
+    """c [L, Mloc, BC] -> xf [Mloc, K, BC] with table[m_off + m] (K3)."""
+
+    @staticmethod
+    def forward(ctx, c, table, nlat, m_off):
+        ctx.save_for_backward(table)
+        ctx.lmax, ctx.m_off = c.shape[0], m_off
+        return legendre_inv_raw(c, table, nlat, m_off)
+
+    @staticmethod
+    def backward(ctx, gxf):
+        (table,) = ctx.saved_tensors
+        return legendre_fwd_raw(gxf.contiguous(), table, ctx.lmax, ctx.m_off), None, None, None
+
+
+class _SpecPack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c_std, l_off, m_off):
+        ctx.offs = (l_off, m_off)
+        return spec_pack_raw(c_std)
+
+    @staticmethod
+    def backward(ctx, g):
+        return spec_unpack_raw(g.contiguous(), *ctx.offs), None, None
+
+
+class _SpecUnpack(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c_prv, l_off, m_off):
+        return spec_unpack_raw(c_prv, l_off, m_off)
+
+    @staticmethod
+    def backward(ctx, g):
+        return spec_pack_raw(g.contiguous()), None, None
+
+
+class _Dhconv(torch.autograd.Function):
+    """y[l, m, b, o] = sum_i x[l, m, b, i] w[i, o, l] on the private layout (K5)."""
+
+    @staticmethod
+    def forward(ctx, x, w, batch, l_off, m_off):
+        wp = _w_phys(w)
+        ctx.save_for_backward(x, wp)
+        ctx.args = (batch, l_off, m_off)
+        return dhconv_fwd_raw(x, wp, batch, l_off, m_off)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, wp = ctx.saved_tensors
+        batch, l_off, m_off = ctx.args
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = dhconv_dgrad_raw(gy, wp, batch, l_off, m_off)
+        if ctx.needs_input_grad[1]:
+            # physical [L, I, O] -> logical [I, O, L] view with the parameter's own strides
+            gw = dhconv_wgrad_raw(x, gy, batch, l_off, m_off).permute(1, 2, 0)
+        return gx, gw, None, None, None
+
+
+def rfft(x, twiddles, mmax):
+    return _RFFT.apply(x, twiddles, mmax)
+
+
+def irfft(xf, twiddles, nlon):
+    return _IRFFT.apply(xf, twiddles, nlon)
+
+
+def legendre_fwd(xf, table, lmax, m_off=0):
+    return _LegendreFwd.apply(xf, table, lmax, m_off)
+
+
+def legendre_inv(c, table, nlat, m_off=0):
+    return _LegendreInv.apply(c, table, nlat, m_off)
+
+
+def spec_pack(c_std, l_off=0, m_off=0):
+    return _SpecPack.apply(c_std, l_off, m_off)
+
+
+def spec_unpack(c_prv, l_off=0, m_off=0):
+    return _SpecUnpack.apply(c_prv, l_off, m_off)
+
+
+def dhconv(x, w, batch, l_off=0, m_off=0):
+    return _Dhconv.apply(x, w, batch, l_off, m_off)

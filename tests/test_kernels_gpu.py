@@ -1,0 +1,291 @@
+"""GPU parity tests of the HIP kernels, called through the C ABI (makani_amd.ops -> ctypes).
+
+Checker: the CPU oracle (oracle/), numpy FFTs and explicit einsums on the same seeded
+inputs.  Tolerance: relative L2 <= 1e-5 in fp32 (BASELINE.json north_star); the
+kernels are exact-fp32 MFMA / VALU so the observed error is ~1e-6 or better.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def rel(a, b):
+    a = np.asarray(a).astype(np.complex128 if np.iscomplexobj(a) or np.iscomplexobj(b) else np.float64)
+    b = np.asarray(b)
+    return np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from makani_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
+
+
+def tril_mask(lmax, mmax, l_off=0, m_off=0):
+    l = np.arange(lmax)[:, None] + l_off
+    m = np.arange(mmax)[None, :] + m_off
+    return (l >= m)
+
+
+# --------------------------------------------------------------------------- FFT
+FFT_CASES = [  # bc, nlat, nlon, mmax
+    (5, 7, 1440, 241),     # production full-res length, odd channel count (ragged tile)
+    (19, 3, 480, 241),     # production low-res length incl. the Nyquist mode
+    (3, 33, 64, 17),
+    (16, 2, 180, 31),
+    (4, 5, 36, 19),        # generic (direct DFT) path, all modes
+    (2, 3, 720, 100),
+    (1, 1, 16, 9),
+]
+
+
+@pytest.mark.parametrize("bc,nlat,nlon,mmax", FFT_CASES)
+def test_rfft_matches_numpy(dev, bc, nlat, nlon, mmax):
+    from makani_amd import ops
+    rng = np.random.default_rng(333)
+    x = rng.standard_normal((bc, nlat, nlon)).astype(np.float32)
+    tw = ops.fft_twiddles(nlon).to(dev)
+    s = 2 * math.pi / nlon
+    xf = ops.rfft_raw(torch.from_numpy(x).to(dev), tw, mmax, s, s, s)
+    want = (2 * np.pi * np.fft.rfft(x.astype(np.float64), axis=-1, norm="forward"))[..., :mmax]
+    got = xf.cpu().numpy().transpose(2, 1, 0)  # [M,K,BC] -> [BC,K,M]
+    assert rel(got, want) < TOL
+    # bf16 input rows: same values after an exact up-cast
+    xb = torch.from_numpy(x).to(dev).to(torch.bfloat16)
+    xfb = ops.rfft_raw(xb, tw, mmax, s, s, s)
+    wantb = (2 * np.pi * np.fft.rfft(xb.float().cpu().numpy().astype(np.float64), axis=-1, norm="forward"))[..., :mmax]
+    assert rel(xfb.cpu().numpy().transpose(2, 1, 0), wantb) < TOL
+
+
+@pytest.mark.parametrize("bc,nlat,nlon,mmax", FFT_CASES)
+def test_irfft_matches_numpy(dev, bc, nlat, nlon, mmax):
+    from makani_amd import ops
+    rng = np.random.default_rng(334)
+    X = (rng.standard_normal((bc, nlat, mmax)) + 1j * rng.standard_normal((bc, nlat, mmax))).astype(np.complex64)
+    tw = ops.fft_twiddles(nlon).to(dev)
+    xf = torch.from_numpy(np.ascontiguousarray(X.transpose(2, 1, 0))).to(dev)
+    x = ops.irfft_raw(xf, tw, nlon, 1.0, 1.0, 1.0)
+    want = np.fft.irfft(X.astype(np.complex128), n=nlon, axis=-1, norm="forward")
+    assert rel(x.cpu().numpy(), want) < TOL
+
+
+@pytest.mark.parametrize("bc,nlat,nlon,mmax", FFT_CASES[:5])
+def test_fft_adjoint_pairs(dev, bc, nlat, nlon, mmax):
+    """<rfft(x), G> == <x, rfft^H G> and the same for irfft, in torch's gradient convention."""
+    from makani_amd import ops
+    g = torch.Generator(device="cpu").manual_seed(5)
+    tw = ops.fft_twiddles(nlon).to(dev)
+    x = torch.randn(bc, nlat, nlon, generator=g).to(dev).requires_grad_(True)
+    G = torch.complex(torch.randn(mmax, nlat, bc, generator=g), torch.randn(mmax, nlat, bc, generator=g)).to(dev)
+    y = ops.rfft(x, tw, mmax)
+    (gx,) = torch.autograd.grad(y, x, G)
+    xr = torch.fft.rfft(x.detach().cpu().double(), dim=-1, norm="forward")[..., :mmax] * 2 * math.pi
+    xr.requires_grad_(False)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    yr = (torch.fft.rfft(xc, dim=-1, norm="forward")[..., :mmax] * 2 * math.pi).permute(2, 1, 0)
+    (gref,) = torch.autograd.grad(yr, xc, G.cpu().to(torch.complex128))
+    assert rel(gx.cpu().numpy(), gref.numpy()) < TOL
+
+    c = torch.complex(torch.randn(mmax, nlat, bc, generator=g), torch.randn(mmax, nlat, bc, generator=g)).to(dev)
+    c.requires_grad_(True)
+    gy = torch.randn(bc, nlat, nlon, generator=g).to(dev)
+    z = ops.irfft(c, tw, nlon)
+    (gc,) = torch.autograd.grad(z, c, gy)
+    cc = c.detach().cpu().to(torch.complex128).requires_grad_(True)
+    zr = torch.fft.irfft(cc.permute(2, 1, 0), n=nlon, dim=-1, norm="forward")
+    (gcref,) = torch.autograd.grad(zr, cc, gy.cpu().double())
+    assert rel(gc.cpu().numpy(), gcref.numpy()) < TOL
+
+
+# --------------------------------------------------------------------------- Legendre
+LEG_CASES = [  # grid, nlat, lmax, mmax, bc
+    ("equiangular", 33, 16, 17, 3),
+    ("legendre-gauss", 32, 32, 33, 4),
+    ("equiangular", 91, 30, 31, 7),       # odd 2*bc/2 -> float2 staging path
+    ("legendre-gauss", 240, 240, 241, 6),  # production low-res
+    ("equiangular", 721, 240, 241, 4),     # production full-res
+    ("equiangular", 65, 70, 40, 66),       # lmax > TM tiles, several column tiles
+]
+
+
+@pytest.mark.parametrize("grid,nlat,lmax,mmax,bc", LEG_CASES)
+def test_legendre_fwd_inv(dev, grid, nlat, lmax, mmax, bc):
+    from makani_amd import ops
+    rng = np.random.default_rng(7)
+    tabw = ops.legendre_table(grid, nlat, lmax, mmax, True)
+    tabp = ops.legendre_table(grid, nlat, lmax, mmax, False)
+    xf = (rng.standard_normal((mmax, nlat, bc)) + 1j * rng.standard_normal((mmax, nlat, bc))).astype(np.complex64)
+    c = ops.legendre_fwd_raw(torch.from_numpy(xf).to(dev), tabw.to(dev), lmax)
+    W = tabw.numpy()[:, :, :nlat].astype(np.float64)
+    want = np.einsum("mlk,mkn->lmn", W, xf.astype(np.complex128))
+    mask = tril_mask(lmax, mmax)[:, :, None]
+    got = np.where(mask, c.cpu().numpy(), 0)
+    assert rel(got, want) < TOL
+    # synthesis: entries with l < m must be ignored whatever they hold
+    cin = (rng.standard_normal((lmax, mmax, bc)) + 1j * rng.standard_normal((lmax, mmax, bc))).astype(np.complex64)
+    y = ops.legendre_inv_raw(torch.from_numpy(cin).to(dev), tabp.to(dev), nlat)
+    P = tabp.numpy()[:, :, :nlat].astype(np.float64)
+    wanty = np.einsum("mlk,lmn->mkn", P, np.where(mask, cin, 0).astype(np.complex128))
+    assert rel(y.cpu().numpy(), wanty) < TOL
+
+
+def test_legendre_mode_shard(dev):
+    """m-sharded launch (w-parallel tables): local modes [m_off, m_off + mloc)."""
+    from makani_amd import ops
+    rng = np.random.default_rng(8)
+    grid, nlat, lmax, mmax, bc = "equiangular", 49, 24, 25, 5
+    tabw = ops.legendre_table(grid, nlat, lmax, mmax, True).to(dev)
+    tabp = ops.legendre_table(grid, nlat, lmax, mmax, False).to(dev)
+    xf = torch.from_numpy((rng.standard_normal((mmax, nlat, bc)) + 1j * rng.standard_normal((mmax, nlat, bc))).astype(np.complex64)).to(dev)
+    full = ops.legendre_fwd_raw(xf, tabw, lmax)
+    m_off, mloc = 9, 11
+    part = ops.legendre_fwd_raw(xf[m_off:m_off + mloc].contiguous(), tabw, lmax, m_off)
+    mask = torch.from_numpy(tril_mask(lmax, mloc, 0, m_off)).to(dev)[:, :, None]
+    assert torch.equal(torch.where(mask, part, 0), torch.where(mask, full[:, m_off:m_off + mloc], 0))
+    cfull = torch.where(torch.from_numpy(tril_mask(lmax, mmax)).to(dev)[:, :, None], full, 0)
+    yfull = ops.legendre_inv_raw(cfull, tabp, nlat)
+    ypart = ops.legendre_inv_raw(cfull[:, m_off:m_off + mloc].contiguous(), tabp, nlat, m_off)
+    assert torch.equal(ypart, yfull[m_off:m_off + mloc])
+
+
+# --------------------------------------------------------------------------- full SHT vs oracle
+SHT_CASES = [("equiangular", 33, 64, 16, 17, (2, 3)), ("legendre-gauss", 32, 64, 32, 33, (5,)),
+             ("equiangular", 91, 180, 30, 31, (1, 2)), ("legendre-gauss", 240, 480, 240, 241, (3,)),
+             ("equiangular", 721, 1440, 240, 241, (2,))]
+
+
+@pytest.mark.parametrize("grid,nlat,nlon,lmax,mmax,lead", SHT_CASES)
+def test_sht_modules_vs_oracle(dev, grid, nlat, nlon, lmax, mmax, lead):
+    from makani_amd.sht import RealSHT, InverseRealSHT
+    from oracle import sht as osht
+    rng = np.random.default_rng(333)
+    x = rng.standard_normal((*lead, nlat, nlon)).astype(np.float32)
+    f = RealSHT(nlat, nlon, lmax, mmax, grid).to(dev).float()
+    fi = InverseRealSHT(nlat, nlon, lmax, mmax, grid).to(dev).float()
+    c = f(torch.from_numpy(x).to(dev))
+    assert c.shape == (*lead, lmax, mmax) and c.dtype == torch.complex64
+    want = osht.RealSHT(nlat, nlon, lmax, mmax, grid, dtype=np.float64)(x)
+    assert rel(c.cpu().numpy(), want) < TOL
+    # exact zeros where l < m, as the reference's zero table entries give
+    cz = c.cpu().numpy()
+    assert np.all(cz[..., ~tril_mask(lmax, mmax)] == 0)
+    y = fi(c)
+    wanty = osht.InverseRealSHT(nlat, nlon, lmax, mmax, grid, dtype=np.float64)(want)
+    assert y.shape == x.shape and y.dtype == torch.float32
+    assert rel(y.cpu().numpy(), wanty) < TOL
+    # projection idempotence (size independent property): sht(isht(sht x)) == sht x
+    c2 = f(y)
+    assert rel(c2.cpu().numpy(), c.cpu().numpy()) < TOL
+
+
+def test_sht_autograd_vs_oracle(dev):
+    from makani_amd.sht import RealSHT, InverseRealSHT
+    from oracle import spectral as osp
+    g = torch.Generator().manual_seed(11)
+    nlat, nlon, lmax, mmax, grid = 33, 64, 16, 17, "equiangular"
+    x = torch.randn(2, 3, nlat, nlon, generator=g)
+    f, fi = RealSHT(nlat, nlon, lmax, mmax, grid).to(dev), InverseRealSHT(nlat, nlon, lmax, mmax, grid).to(dev)
+    fo, fio = osp.TorchRealSHT(nlat, nlon, lmax, mmax, grid), osp.TorchInverseRealSHT(nlat, nlon, lmax, mmax, grid)
+    xd = x.to(dev).requires_grad_(True)
+    xo = x.clone().requires_grad_(True)
+    wgt = torch.randn(2, 3, nlat, nlon, generator=g)
+    cw = torch.complex(torch.randn(2, 3, lmax, mmax, generator=g), torch.randn(2, 3, lmax, mmax, generator=g))
+    c = f(xd)
+    loss = (fi(c) * wgt.to(dev)).sum() + (c * cw.to(dev)).real.sum()
+    loss.backward()
+    co = fo(xo)
+    losso = (fio(co) * wgt).sum() + (co * cw).real.sum()
+    losso.backward()
+    assert abs(loss.item() - losso.item()) / abs(losso.item()) < 1e-4
+    assert rel(xd.grad.cpu().numpy(), xo.grad.numpy()) < TOL
+
+
+# --------------------------------------------------------------------------- dhconv
+DH_CASES = [  # L, M, B, I, O, l_off, m_off
+    (16, 17, 2, 6, 5, 0, 0),       # odd O -> float2 path
+    (12, 13, 1, 8, 8, 0, 0),
+    (40, 41, 3, 24, 40, 0, 0),     # several row tiles
+    (10, 21, 2, 16, 12, 20, 0),    # l shard (h-parallel)
+    (30, 11, 1, 12, 16, 0, 15),    # m shard (w-parallel): low degrees have no valid mode
+    (70, 71, 1, 72, 130, 0, 0),    # > 1 column tile, ragged
+]
+
+
+def _dh_ref(x, w, l_off, m_off):
+    # x [L,M,B,I], w [I,O,L] -> y [L,M,B,O], zero where l < m
+    y = np.einsum("lmbi,iol->lmbo", x.astype(np.complex128), w.astype(np.complex128))
+    mask = tril_mask(x.shape[0], x.shape[1], l_off, m_off)[:, :, None, None]
+    return np.where(mask, y, 0), mask
+
+
+@pytest.mark.parametrize("L,M,B,I,O,l_off,m_off", DH_CASES)
+def test_dhconv_fwd_bwd(dev, L, M, B, I, O, l_off, m_off):
+    from makani_amd import ops
+    rng = np.random.default_rng(21)
+
+    def crand(*s):
+        return (rng.standard_normal(s) + 1j * rng.standard_normal(s)).astype(np.complex64)
+
+    x, w, gy = crand(L, M, B, I), crand(I, O, L), crand(L, M, B, O)
+    want, mask = _dh_ref(x, w, l_off, m_off)
+    wphys = torch.from_numpy(np.ascontiguousarray(w.transpose(2, 0, 1))).to(dev)
+    xd = torch.from_numpy(x.reshape(L, M, B * I)).to(dev)
+    y = ops.dhconv_fwd_raw(xd, wphys, B, l_off, m_off).cpu().numpy().reshape(L, M, B, O)
+    assert rel(np.where(mask, y, 0), want) < TOL
+    # dgrad / wgrad against the analytic adjoints (torch convention: conj on the other operand)
+    gyd = torch.from_numpy(gy.reshape(L, M, B * O)).to(dev)
+    gym = np.where(mask, gy, 0).astype(np.complex128)
+    gx = ops.dhconv_dgrad_raw(gyd, wphys, B, l_off, m_off).cpu().numpy().reshape(L, M, B, I)
+    want_gx = np.einsum("lmbo,iol->lmbi", gym, np.conj(w).astype(np.complex128))
+    assert rel(np.where(mask, gx, 0), want_gx) < TOL
+    gw = ops.dhconv_wgrad_raw(xd, gyd, B, l_off, m_off).cpu().numpy()  # [L,I,O]
+    want_gw = np.einsum("lmbi,lmbo->lio", np.conj(np.where(mask, x, 0)).astype(np.complex128), gym)
+    assert rel(gw, want_gw) < TOL
+
+
+def test_dhconv_autograd_matches_reference_einsum(dev, golden_dir):
+    """The op behind the reference's `_contract_dhconv` golden vector + torch autograd parity."""
+    import os
+    from makani_amd import ops
+    g = np.load(os.path.join(golden_dir, "ref_contractions.npz"))
+    x, w, want = g["x"], g["w_dhconv"], g["y_dhconv"]       # x [B,I,X,Y], w [I,O,X]
+    B, I, X, Y = x.shape
+    O = w.shape[1]
+    xt = torch.from_numpy(x).to(dev).requires_grad_(True)
+    wt = torch.from_numpy(w).to(dev).requires_grad_(True)
+    xp = ops.spec_pack(xt.reshape(B * I, X, Y))
+    yp = ops.dhconv(xp, wt, B)
+    y = ops.spec_unpack(yp).reshape(B, O, X, Y)
+    mask = tril_mask(X, Y)
+    assert rel(np.where(mask, y.detach().cpu().numpy(), 0), np.where(mask, want, 0)) < TOL
+    gy = torch.from_numpy(np.where(mask, g["y_diagonal"][:, :O], 0).astype(np.complex64)).to(dev)
+    y.backward(gy)
+    xo = torch.from_numpy(np.where(mask, x, 0)).requires_grad_(True)
+    wo = torch.from_numpy(w).requires_grad_(True)
+    yo = torch.einsum("bixy,iox->boxy", xo, wo)
+    yo.backward(gy.cpu())
+    assert rel(np.where(mask, xt.grad.cpu().numpy(), 0), xo.grad.numpy()) < TOL
+    assert rel(wt.grad.cpu().numpy(), wo.grad.numpy()) < TOL
+
+
+# --------------------------------------------------------------------------- layout
+@pytest.mark.parametrize("bc,L,M", [(3, 16, 17), (70, 33, 40), (1, 1, 1)])
+def test_pack_unpack(dev, bc, L, M):
+    from makani_amd import ops
+    rng = np.random.default_rng(2)
+    c = (rng.standard_normal((bc, L, M)) + 1j * rng.standard_normal((bc, L, M))).astype(np.complex64)
+    ct = torch.from_numpy(c).to(dev)
+    p = ops.spec_pack_raw(ct)
+    assert np.array_equal(p.cpu().numpy(), c.transpose(1, 2, 0))
+    u = ops.spec_unpack_raw(p, 0, 0).cpu().numpy()
+    assert np.array_equal(u, np.where(tril_mask(L, M), c, 0))
+    u2 = ops.spec_unpack_raw(p, 3, 5).cpu().numpy()
+    assert np.array_equal(u2, np.where(tril_mask(L, M, 3, 5), c, 0))
