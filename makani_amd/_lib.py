@@ -6,6 +6,11 @@ built because hipcc is absent) importing any compute entry point raises.
 import ctypes
 import os
 
+# torch must be loaded first: libmakani_amd.so needs libamdhip64.so.7 and has to bind to the SAME HIP
+# runtime instance torch brought (its streams and allocations are what the kernels receive); loading
+# the extension first would pull a second runtime from /opt/rocm into the process.
+import torch  # noqa: F401
+
 from . import build as _build
 
 _LIB = None

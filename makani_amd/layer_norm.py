@@ -1,0 +1,62 @@
+"""Instance norm over a spatially sharded field.
+
+Mirrors ``makani/mpu/layer_norm.py:27-114`` (``DistributedInstanceNorm2d``): local
+(var, mean, count) per (b, c), merged across the ``spatial`` group with Welford's
+update, then normalise + affine.  Differences, both documented in DESIGN.md:
+
+* the three per-rank statistics travel in ONE all-gather (``[B, C, 3]``) instead of three;
+* statistics keep their batch dimension (``[B, C, 1, 1]``); the reference reshapes to
+  ``(1, -1, 1, 1)`` (layer_norm.py:85-86), which is only valid for local batch 1.
+"""
+import torch
+import torch.nn as nn
+
+from . import comm
+from .mappings import copy_to_parallel_region, gather_from_parallel_region
+
+
+class DistributedInstanceNorm2d(nn.Module):
+    def __init__(self, num_features, eps=1e-05, affine=False, device=None, dtype=None):
+        super().__init__()
+        self.eps = eps
+        self.affine = affine
+        if self.affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+            self.weight.is_shared_mp = ["spatial"]
+            self.bias.is_shared_mp = ["spatial"]
+
+    def _stats_welford(self, x):
+        var, mean = torch.var_mean(x, dim=(-2, -1), unbiased=False, keepdim=False)   # [B, C]
+        count = torch.full_like(mean, float(x.shape[-2] * x.shape[-1]))
+        stats = torch.stack([var, mean, count], dim=-1).unsqueeze(-1)               # [B, C, 3, 1]
+        stats = gather_from_parallel_region(stats, -1, None, "spatial")              # [B, C, 3, P]
+        vars_, means, counts = stats[:, :, 0], stats[:, :, 1], stats[:, :, 2]
+        m2s = vars_ * counts
+        mean, m2, count = means[..., 0], m2s[..., 0], counts[..., 0]
+        for i in range(1, comm.get_size("spatial")):
+            delta = means[..., i] - mean
+            m2 = m2 + m2s[..., i] + delta**2 * count * counts[..., i] / (count + counts[..., i])
+            if i == 1:
+                mean = (mean * count + means[..., i] * counts[..., i]) / (count + counts[..., i])
+            else:
+                mean = mean + delta * counts[..., i] / (count + counts[..., i])
+            count = count + counts[..., i]
+        var = m2 / count
+        return var.unsqueeze(-1).unsqueeze(-1), mean.unsqueeze(-1).unsqueeze(-1)
+
+    def forward(self, x):
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            dtype = x.dtype
+            xf = x.float()
+            var, mean = self._stats_welford(xf)
+            # gradients of the (replicated) statistics are summed over the spatial group
+            mean = copy_to_parallel_region(mean, "spatial")
+            var = copy_to_parallel_region(var, "spatial")
+        x = xf.to(dtype)
+        mean = mean.to(dtype)
+        var = var.to(dtype)
+        x = (x - mean) / torch.sqrt(var + self.eps)
+        if self.affine:
+            x = self.weight.reshape(-1, 1, 1) * x + self.bias.reshape(-1, 1, 1)
+        return x

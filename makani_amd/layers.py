@@ -1,0 +1,175 @@
+"""Glue layers that run between the spectral ops: encoder/decoder, MLP, DropPath, FFT wrappers.
+
+Same constructor arguments, initialisation and ``state_dict`` keys as
+``makani/models/common/layers.py:35-287``.  Pointwise 1x1 convolutions are evaluated as
+one GEMM over the NCHW field viewed as ``[C, H*W]`` (hipBLASLt through torch) -- the
+parameters stay ``nn.Conv2d`` weights ``[O, I, 1, 1]`` so reference checkpoints load.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+from torch.utils.checkpoint import checkpoint
+
+
+class Conv1x1(nn.Conv2d):
+    """``nn.Conv2d(cin, cout, 1)`` evaluated as ``W @ x.view(B, C, H*W)`` (+ bias)."""
+
+    def __init__(self, in_channels, out_channels, bias=True):
+        super().__init__(in_channels, out_channels, 1, bias=bias)
+
+    def forward(self, x):
+        if x.dim() != 4 or not x.is_contiguous():
+            return F.conv2d(x, self.weight, self.bias)
+        B, C, H, W = x.shape
+        w = self.weight.view(self.out_channels, self.in_channels)
+        y = torch.matmul(w, x.view(B, C, H * W))
+        if self.bias is not None:
+            y = y + self.bias.to(y.dtype).view(1, -1, 1)
+        return y.view(B, self.out_channels, H, W)
+
+
+def drop_path(x, drop_prob=0.0, training=False):
+    if drop_prob == 0.0 or not training:
+        return x
+    keep_prob = 1.0 - drop_prob
+    shape = (x.shape[0],) + (1,) * (x.ndim - 1)
+    random_tensor = keep_prob + torch.rand(shape, dtype=x.dtype, device=x.device)
+    random_tensor.floor_()
+    return x.div(keep_prob) * random_tensor
+
+
+class DropPath(nn.Module):
+    def __init__(self, drop_prob=None):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x):
+        return drop_path(x, self.drop_prob, self.training)
+
+
+class EncoderDecoder(nn.Module):
+    """layers.py:86-133."""
+
+    def __init__(self, num_layers, input_dim, output_dim, hidden_dim, act_layer, gain=1.0, input_format="nchw"):
+        super().__init__()
+        if input_format not in ("nchw", "traditional"):
+            raise NotImplementedError(f"Error, input format {input_format} not supported.")
+        mods = []
+        current_dim = input_dim
+        for _ in range(num_layers):
+            if input_format == "nchw":
+                mods.append(Conv1x1(current_dim, hidden_dim, bias=True))
+            else:
+                mods.append(nn.Linear(current_dim, hidden_dim, bias=True))
+            mods[-1].weight.is_shared_mp = ["spatial"]
+            nn.init.normal_(mods[-1].weight, mean=0.0, std=math.sqrt(2.0 / current_dim))
+            if mods[-1].bias is not None:
+                mods[-1].bias.is_shared_mp = ["spatial"]
+                nn.init.constant_(mods[-1].bias, 0.0)
+            mods.append(act_layer())
+            current_dim = hidden_dim
+        if input_format == "nchw":
+            mods.append(Conv1x1(current_dim, output_dim, bias=False))
+        else:
+            mods.append(nn.Linear(current_dim, output_dim, bias=False))
+        mods[-1].weight.is_shared_mp = ["spatial"]
+        nn.init.normal_(mods[-1].weight, mean=0.0, std=math.sqrt(gain / current_dim))
+        self.fwd = nn.Sequential(*mods)
+
+    def forward(self, x):
+        return self.fwd(x)
+
+
+class MLP(nn.Module):
+    """layers.py:136-216."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, output_bias=True,
+                 input_format="nchw", drop_rate=0.0, drop_type="iid", checkpointing=0, gain=1.0, **kwargs):
+        super().__init__()
+        self.checkpointing = checkpointing
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        if input_format == "nchw":
+            fc1 = Conv1x1(in_features, hidden_features, bias=True)
+            fc1.weight.is_shared_mp = ["spatial"]
+            fc1.bias.is_shared_mp = ["spatial"]
+        elif input_format == "traditional":
+            fc1 = nn.Linear(in_features, hidden_features, bias=True)
+        else:
+            raise NotImplementedError(f"Error, input format {input_format} not supported.")
+        nn.init.normal_(fc1.weight, mean=0.0, std=math.sqrt(2.0 / in_features))
+        nn.init.constant_(fc1.bias, 0.0)
+        act = act_layer()
+        if (input_format == "traditional") and (drop_type == "features"):
+            raise NotImplementedError("Error, traditional input format and feature dropout cannot be selected simultaneously")
+        if input_format == "nchw":
+            fc2 = Conv1x1(hidden_features, out_features, bias=output_bias)
+            fc2.weight.is_shared_mp = ["spatial"]
+            if output_bias:
+                fc2.bias.is_shared_mp = ["spatial"]
+        else:
+            fc2 = nn.Linear(hidden_features, out_features, bias=output_bias)
+        nn.init.normal_(fc2.weight, mean=0.0, std=math.sqrt(gain / hidden_features))
+        if fc2.bias is not None:
+            nn.init.constant_(fc2.bias, 0.0)
+        if drop_rate > 0.0:
+            if drop_type == "iid":
+                drop = nn.Dropout(drop_rate)
+            elif drop_type == "features":
+                drop = nn.Dropout2d(drop_rate)
+            else:
+                raise NotImplementedError(f"Error, drop_type {drop_type} not supported")
+        else:
+            drop = nn.Identity()
+        self.fwd = nn.Sequential(fc1, act, drop, fc2, drop)
+
+    def checkpoint_forward(self, x):
+        return checkpoint(self.fwd, x, use_reentrant=False)
+
+    def forward(self, x):
+        if self.checkpointing >= 2:
+            return self.checkpoint_forward(x)
+        return self.fwd(x)
+
+
+class RealFFT2(nn.Module):
+    """layers.py:219-250 -- the duck-typed planar transform (torch.fft; not on the SFNO path)."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None):
+        super().__init__()
+        self.nlat, self.nlon = nlat, nlon
+        self.lmax = min(lmax or self.nlat, self.nlat)
+        self.mmax = min(mmax or self.nlon // 2 + 1, self.nlon // 2 + 1)
+        self.truncate = not ((self.lmax == self.nlat) and (self.mmax == (self.nlon // 2 + 1)))
+        self.lmax_high = math.ceil(self.lmax / 2)
+        self.lmax_low = math.floor(self.lmax / 2)
+
+    def forward(self, x):
+        y = torch.fft.rfft2(x, s=(self.nlat, self.nlon), dim=(-2, -1), norm="ortho")
+        if self.truncate:
+            y = torch.cat((y[..., : self.lmax_high, : self.mmax], y[..., -self.lmax_low:, : self.mmax]), dim=-2)
+        return y
+
+
+class InverseRealFFT2(nn.Module):
+    """layers.py:253-287."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None):
+        super().__init__()
+        self.nlat, self.nlon = nlat, nlon
+        self.lmax = min(lmax or self.nlat, self.nlat)
+        self.mmax = min(mmax or self.nlon // 2 + 1, self.nlon // 2 + 1)
+        self.truncate = not ((self.lmax == self.nlat) and (self.mmax == (self.nlon // 2 + 1)))
+        self.lmax_high = math.ceil(self.lmax / 2)
+        self.lmax_low = math.floor(self.lmax / 2)
+
+    def forward(self, x):
+        xt = x[..., : self.mmax]
+        if self.truncate:
+            xth = xt[..., : self.lmax_high, :]
+            xtl = xt[..., -self.lmax_low:, :]
+            xthp = F.pad(xth, (0, 0, 0, self.nlat - self.lmax))
+            xt = torch.cat([xthp, xtl], dim=-2)
+        return torch.fft.irfft2(xt, s=(self.nlat, self.nlon), dim=(-2, -1), norm="ortho")

@@ -1,0 +1,149 @@
+"""Autograd-aware collectives for model parallel regions + shared-weight gradient reduction.
+
+Restates what the reference takes from ``modulus.distributed.mappings``
+(``copy_to_parallel_region`` / ``gather_from_parallel_region`` ..., used at
+``makani/mpu/layer_norm.py:25,48-51,100-101``) and the gradient reduction of
+``makani/mpu/mappings.py:30-174`` (SUM over every model-parallel group a parameter is
+shared on, AVG over ``data``; complex gradients viewed as real), without DDP: the
+reduction is one flattened all-reduce per group issued after backward.
+"""
+import torch
+import torch.distributed as dist
+from torch._utils import _flatten_dense_tensors, _unflatten_dense_tensors
+
+from . import comm
+
+
+class _CopyToParallelRegion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, name):
+        ctx.name = name
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        if comm.get_size(ctx.name) > 1:
+            g = g.contiguous().clone()
+            dist.all_reduce(g, group=comm.get_group(ctx.name))
+        return g, None
+
+
+class _ReduceFromParallelRegion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, name):
+        if comm.get_size(name) > 1:
+            x = x.contiguous().clone()
+            dist.all_reduce(x, group=comm.get_group(name))
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+class _GatherFromParallelRegion(torch.autograd.Function):
+    """all-gather along ``dim`` (uneven shards allowed); backward keeps the own shard."""
+
+    @staticmethod
+    def forward(ctx, x, dim, shapes, name):
+        size, rank = comm.get_size(name), comm.get_rank(name)
+        ctx.dim, ctx.rank = dim, rank
+        if size == 1:
+            ctx.shapes = [x.shape[dim]]
+            return x
+        if shapes is None:
+            shapes = [x.shape[dim]] * size
+        ctx.shapes = list(shapes)
+        x = x.contiguous()
+        outs = []
+        for s in shapes:
+            shp = list(x.shape)
+            shp[dim] = s
+            outs.append(torch.empty(shp, dtype=x.dtype, device=x.device))
+        dist.all_gather(outs, x, group=comm.get_group(name))
+        return torch.cat(outs, dim=dim)
+
+    @staticmethod
+    def backward(ctx, g):
+        return torch.split(g, ctx.shapes, dim=ctx.dim)[ctx.rank].contiguous(), None, None, None
+
+
+class _ScatterToParallelRegion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dim, name):
+        from .distributed import compute_split_shapes
+        size, rank = comm.get_size(name), comm.get_rank(name)
+        ctx.dim, ctx.name = dim, name
+        ctx.shapes = compute_split_shapes(x.shape[dim], size)
+        return torch.split(x, ctx.shapes, dim=dim)[rank].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _GatherFromParallelRegion.apply(g, ctx.dim, ctx.shapes, ctx.name), None, None
+
+
+def copy_to_parallel_region(x, name):
+    return _CopyToParallelRegion.apply(x, name)
+
+
+def reduce_from_parallel_region(x, name):
+    return _ReduceFromParallelRegion.apply(x, name)
+
+
+def gather_from_parallel_region(x, dim, shapes, name):
+    return _GatherFromParallelRegion.apply(x, dim, shapes, name)
+
+
+def scatter_to_parallel_region(x, dim, name):
+    return _ScatterToParallelRegion.apply(x, dim, name)
+
+
+def _coalesced_all_reduce(grads, group, op):
+    real = [torch.view_as_real(g) if g.is_complex() else g for g in grads]
+    by_dtype = {}
+    for g in real:
+        by_dtype.setdefault(g.dtype, []).append(g)
+    for gs in by_dtype.values():
+        gs_c = [g.contiguous() for g in gs]
+        flat = _flatten_dense_tensors(gs_c)
+        dist.all_reduce(flat, op=op, group=group)
+        for dst, src in zip(gs, _unflatten_dense_tensors(flat, gs_c)):
+            dst.copy_(src)
+
+
+def reduce_shared_gradients(model):
+    """Post-backward gradient reduction with the semantics of mpu/mappings.py:104-169.
+
+    * every parameter: AVG over ``data``;
+    * a parameter annotated ``is_shared_mp = [names]``: SUM over each named group of
+      size > 1 (un-annotated parameters count as shared over ``model``).
+    Parameters sharded over a group (the dhconv weights over ``h``) are not reduced
+    over it.  Call between ``loss.backward()`` and ``optimizer.step()``.
+    """
+    if not dist.is_initialized() or comm.get_world_size() == 1:
+        return
+    params = [p for p in model.parameters() if p.grad is not None]
+    if comm.get_size("data") > 1:
+        _coalesced_all_reduce([p.grad.data for p in params], comm.get_group("data"), dist.ReduceOp.AVG)
+    for name in comm.get_names():
+        if name == "data" or comm.get_size(name) == 1:
+            continue
+        grads = [p.grad.data for p in params if name in getattr(p, "is_shared_mp", ["model"])]
+        if grads:
+            _coalesced_all_reduce(grads, comm.get_group(name), dist.ReduceOp.SUM)
+
+
+def sync_params(model):
+    """Broadcast shared parameters from each group's root (mpu/helpers.py:59-103, simplified)."""
+    if not dist.is_initialized() or comm.get_world_size() == 1:
+        return
+    with torch.no_grad():
+        for p in model.parameters():
+            names = getattr(p, "is_shared_mp", ["model"])
+            for name in list(names) + ["data"]:
+                if comm.get_size(name) > 1:
+                    t = torch.view_as_real(p.data) if p.is_complex() else p.data
+                    tc = t.contiguous()
+                    dist.broadcast(tc, src=comm.get_root(name), group=comm.get_group(name))
+                    if tc.data_ptr() != t.data_ptr():
+                        t.copy_(tc)

@@ -1,0 +1,234 @@
+"""SpectralConv / FactorizedSpectralConv on MI355X.
+
+Mirrors ``makani/models/common/spectral_convolution.py:43-265``: same constructor
+arguments, ``weight`` shape / init / ``is_shared_mp`` / ``sharded_dims_mp`` annotations,
+``forward(x) -> (x, residual)`` with the cast / autocast-off structure of lines 124-148.
+
+When both transforms are this package's HIP transforms and ``operator_type="dhconv"``
+the layer runs fused on the private channels-last spectrum: FFT -> Legendre (MFMA)
+-> dhconv (MFMA) -> Legendre -> FFT, five to seven launches, no layout round trip and no
+``.contiguous()`` copies.  Any other duck-typed transform pair (e.g. ``RealFFT2``) takes
+the generic path through ``get_contract_fun``.
+
+The dhconv weight keeps the reference's logical shape ``[in, out, l]`` (state-dict
+parity) but is *stored* ``[l, in, out]`` (a permuted view), so each degree's
+``in x out`` matrix is one contiguous 1.18 MB panel for the per-degree GEMM.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import comm, ops
+from .contractions import get_contract_fun
+from .distributed import DistributedInverseRealSHT, DistributedRealSHT
+from .sht import InverseRealSHT, RealSHT
+
+
+def _is_hip_pair(fwd, inv):
+    return isinstance(fwd, (RealSHT, DistributedRealSHT)) and isinstance(inv, (InverseRealSHT, DistributedInverseRealSHT))
+
+
+class SpectralConv(nn.Module):
+    def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, operator_type="diagonal",
+                 separable=False, bias=False, gain=1.0):
+        super().__init__()
+        self.forward_transform = forward_transform
+        self.inverse_transform = inverse_transform
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.modes_lat = self.inverse_transform.lmax
+        self.modes_lon = self.inverse_transform.mmax
+        self.scale_residual = (self.forward_transform.nlat != self.inverse_transform.nlat) or \
+                              (self.forward_transform.nlon != self.inverse_transform.nlon)
+        if hasattr(self.forward_transform, "grid"):
+            self.scale_residual = self.scale_residual or (self.forward_transform.grid != self.inverse_transform.grid)
+        self.operator_type = operator_type
+        self.separable = separable
+        assert self.inverse_transform.lmax == self.modes_lat
+        assert self.inverse_transform.mmax == self.modes_lon
+
+        weight_shape = [in_channels]
+        if not self.separable:
+            weight_shape += [out_channels]
+
+        self._distributed = isinstance(self.inverse_transform, DistributedInverseRealSHT)
+        if self._distributed:
+            self.modes_lat_local = self.inverse_transform.l_shapes[comm.get_rank("h")]
+            self.modes_lon_local = self.inverse_transform.m_shapes[comm.get_rank("w")]
+            self.nlat_local = self.inverse_transform.lat_shapes[comm.get_rank("h")]
+            self.nlon_local = self.inverse_transform.lon_shapes[comm.get_rank("w")]
+            self.l_off, self.m_off = self.inverse_transform.l_off, self.inverse_transform.m_off
+        else:
+            self.modes_lat_local = self.modes_lat
+            self.modes_lon_local = self.modes_lon
+            self.nlat_local = self.inverse_transform.nlat
+            self.nlon_local = self.inverse_transform.nlon
+            self.l_off, self.m_off = 0, 0
+
+        if self.operator_type == "diagonal":
+            weight_shape += [self.modes_lat_local, self.modes_lon_local]
+        elif self.operator_type == "dhconv":
+            weight_shape += [self.modes_lat_local]
+        else:
+            raise ValueError(f"Unsupported operator type f{self.operator_type}")
+
+        # same initialisation as spectral_convolution.py:98-101 (note: the scale vector has one entry per
+        # degree l and multiplies the LAST axis, which for "diagonal" is m -- a reference quirk that only
+        # broadcasts when modes_lat == modes_lon; kept as is)
+        scale = math.sqrt(gain / in_channels) * torch.ones(self.modes_lat_local, dtype=torch.complex64)
+        scale[0] *= math.sqrt(2.0)
+        init = scale * torch.randn(*weight_shape, dtype=torch.complex64)
+        if self.operator_type == "dhconv" and not self.separable:
+            # logical [in, out, l], physical [l, in, out]
+            phys = init.permute(2, 0, 1).contiguous()
+            self.weight = nn.Parameter(phys.permute(1, 2, 0))
+        else:
+            self.weight = nn.Parameter(init)
+
+        if self.operator_type == "dhconv":
+            self.weight.is_shared_mp = ["matmul", "w"]
+            self.weight.sharded_dims_mp = [None for _ in weight_shape]
+            self.weight.sharded_dims_mp[-1] = "h"
+        else:
+            self.weight.is_shared_mp = ["matmul"]
+            self.weight.sharded_dims_mp = [None for _ in weight_shape]
+            self.weight.sharded_dims_mp[-1] = "w"
+            self.weight.sharded_dims_mp[-2] = "h"
+
+        self._contract = get_contract_fun(self.weight, implementation="factorized", separable=separable,
+                                          complex=True, operator_type=operator_type)
+        self._fused = _is_hip_pair(forward_transform, inverse_transform) and operator_type == "dhconv" and not separable
+
+        if bias == "constant":
+            self.bias = nn.Parameter(torch.zeros(1, self.out_channels, 1, 1))
+        elif bias == "position":
+            self.bias = nn.Parameter(torch.zeros(1, self.out_channels, self.nlat_local, self.nlon_local))
+            self.bias.is_shared_mp = ["matmul"]
+            self.bias.sharded_dims_mp = [None, None, "h", "w"]
+
+    # -- fused path on the private spectrum -------------------------------------------------
+    def _weight_tensor(self):
+        return self.weight
+
+    def _forward_fused(self, x, dtype):
+        B, C = x.shape[0], x.shape[1]
+        ft, it = self.forward_transform, self.inverse_transform
+        xin = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
+        xin = xin.contiguous()
+        if isinstance(ft, DistributedRealSHT):
+            c = ft.forward_packed(xin)
+        else:
+            c = ft.forward_packed(xin.view(B * C, xin.shape[2], xin.shape[3]))
+        residual = x
+        if self.scale_residual:
+            r = it.inverse_packed(c, B) if self._distributed else it.inverse_packed(c)
+            residual = r.view(B, C, r.shape[-2], r.shape[-1]).to(dtype)
+        y = ops.dhconv(c, self._weight_tensor(), B, self.l_off, self.m_off)
+        out = it.inverse_packed(y, B) if self._distributed else it.inverse_packed(y)
+        out = out.view(B, self.out_channels, out.shape[-2], out.shape[-1])
+        return out, residual
+
+    def forward(self, x):
+        dtype = x.dtype
+        residual = x
+        if self._fused and x.is_cuda and x.dim() == 4:
+            with torch.autocast(device_type="cuda", enabled=False):
+                x, residual = self._forward_fused(x, dtype)
+        else:
+            x = x.float()
+            with torch.autocast(device_type=x.device.type, enabled=False):
+                x = self.forward_transform(x).contiguous()
+                if self.scale_residual:
+                    residual = self.inverse_transform(x)
+                    residual = residual.to(dtype)
+            xp = self._contract(x, self._weight_tensor(), separable=self.separable, operator_type=self.operator_type)
+            x = xp.contiguous()
+            with torch.autocast(device_type=x.device.type, enabled=False):
+                x = self.inverse_transform(x)
+        if hasattr(self, "bias"):
+            x = x + self.bias
+        x = x.to(dtype=dtype)
+        return x, residual
+
+
+class _DenseFactorizedWeight(nn.Module):
+    """Stand-in for ``tltorch.FactorizedTensor.new(shape, rank, factorization="ComplexDense")``.
+
+    tensorly-torch is not available; the dense ("ComplexDense" / "Dense") factorization is the
+    only one built -- it holds one full tensor and ``to_tensor()`` returns it.
+    """
+
+    def __init__(self, shape, complex=True):
+        super().__init__()
+        dtype = torch.complex64 if complex else torch.float32
+        self.shape = tuple(shape)
+        self.name = "ComplexDense" if complex else "Dense"
+        self.tensor = nn.Parameter(torch.empty(*shape, dtype=dtype))
+
+    def normal_(self, mean=0.0, std=1.0):
+        with torch.no_grad():
+            if self.tensor.is_complex():
+                self.tensor.copy_(mean + std * torch.randn(self.shape, dtype=torch.complex64))
+            else:
+                self.tensor.normal_(mean, std)
+        return self
+
+    def to_tensor(self):
+        return self.tensor
+
+
+class FactorizedSpectralConv(SpectralConv):
+    """spectral_convolution.py:151-265 for the dense factorization.
+
+    ``weight`` is a factorized-tensor object whose ``to_tensor()`` is reconstructed every call
+    and contracted exactly like ``SpectralConv`` (``_contract_dense_reconstruct``,
+    factorizations.py:203-209).  CP / Tucker / TT need tensorly-torch and raise.
+    """
+
+    def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, operator_type="diagonal",
+                 rank=0.2, factorization=None, separable=False, decomposition_kwargs=dict(), bias=False, gain=1.0):
+        super().__init__(forward_transform, inverse_transform, in_channels, out_channels, operator_type=operator_type,
+                         separable=separable, bias=bias, gain=gain)
+        if factorization is None:
+            factorization = "ComplexDense"
+        complex_weight = factorization[:7].lower() == "complex"
+        if factorization.lower() not in ("complexdense", "dense"):
+            raise NotImplementedError(f"factorization {factorization} needs tensorly-torch (absent); "
+                                      "only the dense factorization is built")
+        self.rank = rank
+        self.factorization = factorization
+        shape = tuple(self.weight.shape)
+        ann = (self.weight.is_shared_mp, self.weight.sharded_dims_mp)
+        del self.weight
+        self.weight = _DenseFactorizedWeight(shape, complex=complex_weight)
+        scale = math.sqrt(gain / float(shape[0]))  # spectral_convolution.py:224-225
+        self.weight.normal_(mean=0.0, std=scale)
+        self.weight.tensor.is_shared_mp, self.weight.tensor.sharded_dims_mp = ann
+        self._complex_weight = complex_weight
+        self._contract = get_contract_fun(self.weight, implementation="reconstructed", separable=separable,
+                                          complex=complex_weight, operator_type=operator_type)
+        self._fused = self._fused and complex_weight
+
+    def _weight_tensor(self):
+        return self.weight.to_tensor()
+
+    def forward(self, x):
+        if self._complex_weight:
+            return super().forward(x)
+        # real factorized weights act on the view_as_real layout (spectral_convolution.py:250-258)
+        dtype = x.dtype
+        residual = x
+        x = x.float()
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x = self.forward_transform(x).contiguous()
+            if self.scale_residual:
+                residual = self.inverse_transform(x).to(dtype)
+        x = torch.view_as_real(x)
+        xp = self._contract(x, self.weight, separable=self.separable, operator_type=self.operator_type)
+        x = torch.view_as_complex(xp.contiguous())
+        with torch.autocast(device_type="cuda" if x.is_cuda else "cpu", enabled=False):
+            x = self.inverse_transform(x)
+        if hasattr(self, "bias"):
+            x = x + self.bias
+        return x.to(dtype=dtype), residual
