@@ -1,0 +1,263 @@
+#!/usr/bin/env python
+"""Headline benchmark: SFNO forward+backward samples/s, 73 channels on 721x1440 (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One step = zero_grad -> forward under bf16 autocast (spectral path fp32, as the reference) ->
+area-weighted MSE loss -> backward -> shared-gradient reduction -> Adam step, on synthetic
+N(0,1) fields of the configuration ``sfno_linear_73chq_sc3_layers8_edim384``
+(/root/reference/config/sfnonet.yaml:162-187: embed_dim 384, 8 layers, scale_factor 3,
+dhconv, instance norm, MLP ratio 2, big skip).  N > 1: latitude sharded over ``h`` =
+N ranks (spatial model parallelism with RCCL all-to-all), global batch N (weak scaling).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+``roofline`` for the dominant hand-written kernel (timed live with HIP events on the launch
+stream inside the timed region) and ``cpu_baseline`` (the oracle on the host cores, N = 1 only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_MFMA_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E spec peak
+
+CONFIG = dict(spectral_transform="sht", model_grid_type="equiangular", sht_grid_type="legendre-gauss",
+              filter_type="linear", operator_type="dhconv", inp_shape=(721, 1440), out_shape=(721, 1440),
+              scale_factor=3, inp_chans=73, out_chans=73, embed_dim=384, num_layers=8, use_mlp=True, mlp_ratio=2,
+              activation_function="gelu", encoder_layers=1, pos_embed="none", normalization_layer="instance_norm",
+              hard_thresholding_fraction=1.0, big_skip=True, separable=False)
+
+
+# ----------------------------------------------------------------------------------------
+# live per-kernel timing: wrap the raw C-ABI launchers of makani_amd.ops with event pairs
+# ----------------------------------------------------------------------------------------
+class KernelTimer:
+    def __init__(self):
+        self.records = []   # (name, work, unit, start_event, end_event)
+        self.enabled = False
+
+    def install(self):
+        from makani_amd import ops
+
+        def tri_pairs(lloc, mloc, l_off, m_off):
+            t = 0
+            for l in range(lloc):
+                t += max(0, min(mloc, l_off + l - m_off + 1))
+            return t
+
+        def wrap(name, fn, work):
+            def inner(*a, **k):
+                if not self.enabled:
+                    return fn(*a, **k)
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                out = fn(*a, **k)
+                e.record()
+                w, unit = work(out, *a, **k)
+                self.records.append((name, w, unit, s, e))
+                return out
+            return inner
+
+        # algorithmic work per launch: only l >= m counted
+        def leg_fwd_work(out, xf, table, lmax, m_off=0):
+            mloc, k, bc = xf.shape
+            return 4.0 * tri_pairs(lmax, mloc, 0, m_off) * k * bc, "flop"
+
+        def leg_inv_work(out, c, table, nlat, m_off=0):
+            lmax, mloc, bc = c.shape
+            return 4.0 * tri_pairs(lmax, mloc, 0, m_off) * nlat * bc, "flop"
+
+        def dh_work(out, a, w_phys, batch, l_off=0, m_off=0):      # fwd / dgrad: second operand is w [L, I, O]
+            lloc, mloc, _ = a.shape
+            return 8.0 * w_phys.shape[1] * w_phys.shape[2] * tri_pairs(lloc, mloc, l_off, m_off) * batch, "flop"
+
+        def dh_wgrad_work(out, x, gy, batch, l_off=0, m_off=0):    # wgrad: out is gw [L, I, O]
+            lloc, mloc, _ = x.shape
+            return 8.0 * out.shape[1] * out.shape[2] * tri_pairs(lloc, mloc, l_off, m_off) * batch, "flop"
+
+        def rfft_work(out, x, tw, mmax, *s):
+            bc, k, n = x.shape
+            return float(k * bc * (x.element_size() * n + 8 * mmax)), "byte"
+
+        def irfft_work(out, xf, tw, nlon, *s):
+            m, k, bc = xf.shape
+            return float(k * bc * (4 * nlon + 8 * m)), "byte"
+
+        def layout_work(out, t, *a):
+            return float(2 * 8 * t.numel()), "byte"
+
+        ops.rfft_raw = wrap("rfft", ops.rfft_raw, rfft_work)
+        ops.irfft_raw = wrap("irfft", ops.irfft_raw, irfft_work)
+        ops.legendre_fwd_raw = wrap("legendre_fwd", ops.legendre_fwd_raw, leg_fwd_work)
+        ops.legendre_inv_raw = wrap("legendre_inv", ops.legendre_inv_raw, leg_inv_work)
+        ops.dhconv_fwd_raw = wrap("dhconv_fwd", ops.dhconv_fwd_raw, dh_work)
+        ops.dhconv_dgrad_raw = wrap("dhconv_dgrad", ops.dhconv_dgrad_raw, dh_work)
+        ops.dhconv_wgrad_raw = wrap("dhconv_wgrad", ops.dhconv_wgrad_raw, dh_wgrad_work)
+        ops.spec_pack_raw = wrap("spec_pack", ops.spec_pack_raw, layout_work)
+        ops.spec_unpack_raw = wrap("spec_unpack", ops.spec_unpack_raw, layout_work)
+
+    def summary(self, steps):
+        agg = {}
+        for name, w, unit, s, e in self.records:
+            d = agg.setdefault(name, {"ms": 0.0, "work": 0.0, "unit": unit, "launches": 0})
+            d["ms"] += s.elapsed_time(e)
+            d["work"] += w
+            d["launches"] += 1
+        out = {}
+        for name, d in agg.items():
+            sec = d["ms"] * 1e-3
+            if d["unit"] == "flop":
+                ach, peak, unit, bound = d["work"] / sec / 1e12, PEAK_MFMA_F32_TFLOPS, "TFLOP/s", "mfma"
+            else:
+                ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+            out[name] = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
+                         "frac": round(ach / peak, 4), "ms_per_step": round(d["ms"] / steps, 3),
+                         "launches_per_step": d["launches"] / steps,
+                         "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
+        return out
+
+
+# ----------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a port of the reference formulation) on the host cores
+# ----------------------------------------------------------------------------------------
+def cpu_baseline():
+    from oracle import spectral as osp
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    torch.set_num_threads(ncores)
+    torch.manual_seed(0)
+    kw = {k: v for k, v in CONFIG.items() if k not in ("spectral_transform", "filter_type", "pos_embed")}
+    kw["num_layers"] = 2   # blocks 0 and 7: every full-resolution op of the 8-layer net
+    net2 = osp.SphericalFourierNeuralOperatorNet(**kw)
+    x = torch.randn(1, 73, 721, 1440)
+    tar = torch.randn(1, 73, 721, 1440)
+    t0 = time.time()
+    loss = ((net2(x) - tar) ** 2).mean()
+    loss.backward()
+    t_outer = time.time() - t0
+    mid = osp.FourierNeuralOperatorBlock(net2.trans, net2.itrans, 384, operator_type="dhconv", mlp_ratio=2,
+                                         norm_layer=(lambda: torch.nn.InstanceNorm2d(384, eps=1e-6, affine=True),) * 2,
+                                         inner_skip="none", outer_skip="linear", use_mlp=True)
+    xm = torch.randn(1, 384, 240, 480, requires_grad=True)
+    t0 = time.time()
+    mid(xm).sum().backward()
+    t_mid = time.time() - t0
+    total = t_outer + 6.0 * t_mid
+    return {"value": round(1.0 / total, 5), "unit": "samples/s", "cores": ncores, "kind": "port",
+            "sample": ("oracle (fp32 torch-CPU restatement of the reference rfft+einsum formulation), B=1: one fwd+bwd of "
+                       f"the net with num_layers=2 (blocks 0 and 7, all full-resolution work: {t_outer:.1f} s) + one "
+                       f"mid-stack 240x480 block fwd+bwd ({t_mid:.1f} s) counted 6x; no optimizer step")}
+
+
+# ----------------------------------------------------------------------------------------
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    args = ap.parse_args()
+
+    from makani_amd import comm, mappings
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from makani_amd import ops
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
+    if world > 1:
+        comm.init(model_parallel_sizes=[world, 1, 1, 1], model_parallel_names=["h", "w", "fin", "fout"])
+    rank = comm.get_world_rank()
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    hsize, hrank = comm.get_size("h"), comm.get_rank("h")
+
+    torch.manual_seed(333)                      # same replicated weights on every rank ...
+    net = SphericalFourierNeuralOperatorNet(**CONFIG).to(dev)
+    mappings.sync_params(net)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+
+    B = world                                   # weak scaling: one sample per GPU
+    lat_loc = net.inp_shape_loc[0]
+    lat_off = sum(net.trans_down.lat_shapes[:hrank]) if hsize > 1 else 0
+    torch.manual_seed(333 + rank)               # ... different synthetic data per rank
+    inp = torch.randn(B, 73, lat_loc, 1440, device=dev)
+    tar = torch.randn(B, 73, lat_loc, 1440, device=dev)
+    _, wq = ops.quadrature("equiangular", 721)
+    wq = torch.from_numpy(wq / wq.sum() / 1440.0).float()[lat_off:lat_off + lat_loc].to(dev).view(1, 1, -1, 1)
+
+    timer = KernelTimer()
+    if not args.no_kernel_timing:
+        timer.install()
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = net(inp)
+        loss = (((pred.float() - tar) ** 2) * wq).sum() / (B * 73)
+        loss.backward()
+        mappings.reduce_shared_gradients(net)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = not args.no_kernel_timing
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    assert math.isfinite(loss.item()), "loss is not finite"
+
+    if rank == 0:
+        kernels = timer.summary(args.steps) if not args.no_kernel_timing else {}
+        roof = None
+        if kernels:
+            dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
+            k = kernels[dom]
+            roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
+                    "frac": k["frac"], "traffic": None, "avg_launch_ms": k["avg_launch_ms"]}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        line = {
+            "metric": "SFNO fwd+bwd samples/sec, 73ch 721x1440",
+            "value": round(B * args.steps / elapsed, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "sfno_linear_73chq_sc3_layers8_edim384 fwd+bwd+Adam, 73ch 721x1440, per-GPU batch 1",
+                       "global_batch": B, "parallelism": f"h{hsize}", "spectral_dtype": "f32"},
+            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "loss": round(loss.item(), 6),
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        comm.cleanup()
+
+
+if __name__ == "__main__":
+    main()

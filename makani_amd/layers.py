@@ -24,7 +24,12 @@ class Conv1x1(nn.Conv2d):
             return F.conv2d(x, self.weight, self.bias)
         B, C, H, W = x.shape
         w = self.weight.view(self.out_channels, self.in_channels)
-        y = torch.matmul(w, x.view(B, C, H * W))
+        # NOTE: torch.matmul(2-D, 3-D) folds through a transposed *copy* of the activation; mm / bmm on
+        # the [C, H*W] row-major view go straight to hipBLASLt with no copy in forward or backward
+        if B == 1:
+            y = torch.mm(w, x.view(C, H * W)).view(1, self.out_channels, H * W)
+        else:
+            y = torch.bmm(w.unsqueeze(0).expand(B, -1, -1), x.view(B, C, H * W))
         if self.bias is not None:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)

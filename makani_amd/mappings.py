@@ -55,12 +55,14 @@ class _GatherFromParallelRegion(torch.autograd.Function):
             shapes = [x.shape[dim]] * size
         ctx.shapes = list(shapes)
         x = x.contiguous()
-        outs = []
-        for s in shapes:
+        big = max(shapes)
+        if x.shape[dim] < big:   # equal-size all_gather (works on every backend): pad, trim after
             shp = list(x.shape)
-            shp[dim] = s
-            outs.append(torch.empty(shp, dtype=x.dtype, device=x.device))
+            shp[dim] = big - x.shape[dim]
+            x = torch.cat([x, x.new_zeros(shp)], dim=dim)
+        outs = [torch.empty_like(x) for _ in shapes]
         dist.all_gather(outs, x, group=comm.get_group(name))
+        outs = [o.narrow(dim, 0, s) for o, s in zip(outs, shapes)]
         return torch.cat(outs, dim=dim)
 
     @staticmethod
