@@ -131,32 +131,85 @@ class KernelTimer:
 # ----------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a port of the reference formulation) on the host cores
 # ----------------------------------------------------------------------------------------
+def _host_cores():
+    """Threads for the CPU leg: the cgroup CPU quota if there is one, else the affinity mask,
+    never more than 16 (a 1-GPU box's host share; its affinity mask shows the whole machine)."""
+    if os.environ.get("MK_CPU_THREADS"):
+        return int(os.environ["MK_CPU_THREADS"])
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return min(n, 16)
+
+
 def cpu_baseline():
+    """Oracle fwd+bwd on the host cores, on a bounded sample of the step (about 20-30 s of CPU work).
+
+    The full E=384 step takes minutes on a CPU, so each class of work is timed at the true
+    grid sizes on a 1/8 .. 1/16 slice along an axis it is exactly linear in (channels for the
+    transforms, latitude rows for the pointwise stack, degrees for dhconv) and scaled back:
+    """
+    import torch.nn as nn
     from oracle import spectral as osp
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    ncores = _host_cores()
     torch.set_num_threads(ncores)
     torch.manual_seed(0)
-    kw = {k: v for k, v in CONFIG.items() if k not in ("spectral_transform", "filter_type", "pos_embed")}
-    kw["num_layers"] = 2   # blocks 0 and 7: every full-resolution op of the 8-layer net
-    net2 = osp.SphericalFourierNeuralOperatorNet(**kw)
-    x = torch.randn(1, 73, 721, 1440)
-    tar = torch.randn(1, 73, 721, 1440)
-    t0 = time.time()
-    loss = ((net2(x) - tar) ** 2).mean()
-    loss.backward()
-    t_outer = time.time() - t0
-    mid = osp.FourierNeuralOperatorBlock(net2.trans, net2.itrans, 384, operator_type="dhconv", mlp_ratio=2,
-                                         norm_layer=(lambda: torch.nn.InstanceNorm2d(384, eps=1e-6, affine=True),) * 2,
-                                         inner_skip="none", outer_skip="linear", use_mlp=True)
-    xm = torch.randn(1, 384, 240, 480, requires_grad=True)
-    t0 = time.time()
-    mid(xm).sum().backward()
-    t_mid = time.time() - t0
-    total = t_outer + 6.0 * t_mid
+    E, L, M = 384, 240, 241
+
+    def fwd_bwd(fn, *xs):
+        xs = [x.requires_grad_(True) for x in xs]
+        t0 = time.time()
+        y = fn(*xs)
+        (y.real if y.is_complex() else y).sum().backward()
+        return time.time() - t0
+
+    def note(msg):
+        print(f"[cpu_baseline] {msg}", file=sys.stderr, flush=True)
+
+    parts = {}
+    # transforms: linear in channels
+    for tag, (K, N, grid, cs) in {"full": (721, 1440, "equiangular", 24), "low": (240, 480, "legendre-gauss", 48)}.items():
+        f, fi = osp.TorchRealSHT(K, N, L, M, grid), osp.TorchInverseRealSHT(K, N, L, M, grid)
+        t_f = fwd_bwd(f, torch.randn(1, cs, K, N)) * (E / cs)
+        t_i = fwd_bwd(fi, torch.complex(torch.randn(1, cs, L, M), torch.randn(1, cs, L, M))) * (E / cs)
+        parts[f"sht_{tag}"], parts[f"isht_{tag}"] = t_f, t_i
+        note(f"{tag}-res SHT {t_f:.2f} s, iSHT {t_i:.2f} s per 384-channel transform (timed on {cs} channels)")
+    # dhconv: linear in degrees
+    ls = 30
+    xs = torch.complex(torch.randn(1, E, ls, M), torch.randn(1, E, ls, M))
+    ws = torch.complex(torch.randn(E, E, ls), torch.randn(E, E, ls))
+    parts["dhconv"] = fwd_bwd(osp.contract_dhconv, xs, ws) * (L / ls)
+    note(f"dhconv {parts['dhconv']:.2f} s per layer (timed on {ls} of {L} degrees)")
+
+    # pointwise stack: linear in latitude rows
+    def block_tail(rows, cols):
+        norm0, norm1 = nn.InstanceNorm2d(E, eps=1e-6, affine=True), nn.InstanceNorm2d(E, eps=1e-6, affine=True)
+        mlp, skip, act = osp.MLP(E, 2 * E), nn.Conv2d(E, E, 1, bias=False), nn.GELU()
+
+        def fn(x, r):
+            return norm1(mlp(act(norm0(x)))) + skip(r)
+        return fwd_bwd(fn, torch.randn(1, E, rows, cols), torch.randn(1, E, rows, cols))
+
+    parts["block_full"] = block_tail(91, 1440) * (721 / 91)
+    parts["block_low"] = block_tail(30, 480) * (240 / 30)
+    enc, dec = osp.EncoderDecoder(1, 73, E, E, nn.GELU), osp.EncoderDecoder(1, E, 73, E, nn.GELU, gain=0.5)
+    res = nn.Conv2d(73, 73, 1, bias=False)
+    parts["enc_dec"] = fwd_bwd(lambda x: dec(enc(x)) + res(x), torch.randn(1, 73, 91, 1440)) * (721 / 91)
+    note(f"pointwise: full-res block {parts['block_full']:.2f} s, low-res block {parts['block_low']:.2f} s, "
+         f"encoder+decoder {parts['enc_dec']:.2f} s")
+    # transform census of one forward: 1 + 7 analyses, 2 + 8 syntheses
+    total = (parts["sht_full"] + 2 * parts["isht_full"] + 7 * parts["sht_low"] + 8 * parts["isht_low"]
+             + 8 * parts["dhconv"] + parts["block_full"] + 7 * parts["block_low"] + parts["enc_dec"])
     return {"value": round(1.0 / total, 5), "unit": "samples/s", "cores": ncores, "kind": "port",
-            "sample": ("oracle (fp32 torch-CPU restatement of the reference rfft+einsum formulation), B=1: one fwd+bwd of "
-                       f"the net with num_layers=2 (blocks 0 and 7, all full-resolution work: {t_outer:.1f} s) + one "
-                       f"mid-stack 240x480 block fwd+bwd ({t_mid:.1f} s) counted 6x; no optimizer step")}
+            "sample": ("oracle (fp32 torch-CPU restatement of the reference's rfft+einsum formulation) fwd+bwd, B=1, no "
+                       "optimizer: each op class timed at the true grid on a slice it is linear in (transforms on 24 / 48 "
+                       "of 384 channels, dhconv on 30 of 240 degrees, pointwise stack on 91 of 721 / 30 of 240 latitude "
+                       f"rows), scaled and summed over the step's op census: {total:.1f} s per sample"),
+            "parts_s": {k: round(v, 3) for k, v in parts.items()}}
 
 
 # ----------------------------------------------------------------------------------------
@@ -187,7 +240,8 @@ def main():
     torch.manual_seed(333)                      # same replicated weights on every rank ...
     net = SphericalFourierNeuralOperatorNet(**CONFIG).to(dev)
     mappings.sync_params(net)
-    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    from makani_amd.optim import FusedAdam
+    opt = FusedAdam(net.parameters(), lr=1e-4)
 
     B = world                                   # weak scaling: one sample per GPU
     lat_loc = net.inp_shape_loc[0]

@@ -14,6 +14,7 @@
 #include "../../include/makani_amd.h"
 
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 
@@ -449,6 +450,8 @@ int launch_irfft(const float* xf, float* x, const float* tw, int bc, int nlat, i
     return 0;
 }
 
+#include "fft_split.h"
+
 }  // namespace
 
 #define MK_FFT_SIZES(X) \
@@ -463,6 +466,12 @@ extern "C" int mk_rfft(const void* x, int x_dtype, float* xf, const float* twidd
     MK_REQUIRE(x_dtype == 0 || x_dtype == 1, "x_dtype must be 0 (fp32) or 1 (bf16)");
     MK_REQUIRE((long long)nlat * mk::ceil_div(bc, 8) < 2147483647LL, "grid too large");
     hipStream_t st = (hipStream_t)stream;
+    const bool split = !fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440);
+    if (split && nlon == 480) {
+        launch_rfft_split<1>(x, x_dtype, xf, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
+    } else if (split) {
+        launch_rfft_split<3>(x, x_dtype, xf, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
+    } else
     switch (nlon / 2) {
 #define X(H, G) \
     case H:     \
@@ -494,6 +503,12 @@ extern "C" int mk_irfft(const float* xf, float* x, const float* twiddles, int bc
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "mmax out of range");
     MK_REQUIRE((long long)nlat * mk::ceil_div(bc, 8) < 2147483647LL, "grid too large");
     hipStream_t st = (hipStream_t)stream;
+    const bool split = !fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440);
+    if (split && nlon == 480) {
+        launch_irfft_split<1>(xf, x, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
+    } else if (split) {
+        launch_irfft_split<3>(xf, x, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
+    } else
     switch (nlon / 2) {
 #define X(H, G) \
     case H:     \
