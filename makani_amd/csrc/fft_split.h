@@ -74,41 +74,55 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
                                                               const float2* __restrict__ tw, int BC, int K, int M,
                                                               float scale0, float scale_m, float scale_h) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2, E = InVec<TIn>::E;
-    constexpr int VPR = N / E, NV = G * VPR, IT = (NV + STHREADS - 1) / STHREADS;
+    // staging unit: S consecutive vectors of E reals = E reals (E/2 complex) of every sub-sequence
+    constexpr int GPR = N / (S * E), NGRP = G * GPR, IT = (NGRP + STHREADS - 1) / STHREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int ntile = (BC + G - 1) / G;
     const int k = blockIdx.x / ntile;
     const int bc0 = (blockIdx.x - k * ntile) * G;
 
-    float vals[IT][E];
+    float vals[IT][S][E];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int v = tid + it * STHREADS;
-        const int g = v / VPR, q = v - g * VPR;
-        const bool ok = (v < NV) && (bc0 + g < BC);
-        if (ok) {
-            InVec<TIn>::load(x + ((size_t)(bc0 + g) * K + k) * N + q * E, vals[it]);
-        } else {
+        const int g = v / GPR, p = v - g * GPR;
+        const bool ok = (v < NGRP) && (bc0 + g < BC);
 #pragma unroll
-            for (int e = 0; e < E; ++e) vals[it][e] = 0.f;
+        for (int c = 0; c < S; ++c) {
+            if (ok) {
+                InVec<TIn>::load(x + ((size_t)(bc0 + g) * K + k) * N + (p * S + c) * E, vals[it][c]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; ++e) vals[it][c][e] = 0.f;
+            }
         }
     }
     float2 tw15[15];
 #pragma unroll
     for (int r = 0; r < 15; ++r) tw15[r] = tw[((tid & 15) * r) * S];
 
-    float* ldsf = reinterpret_cast<float*>(lds);
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int v = tid + it * STHREADS;
-        if (v < NV) {
-            const int g = v / VPR, q = v - g * VPR;
+        if (v < NGRP) {
+            const int g = v / GPR, p = v - g * GPR;
+            // flat element f = c*E + e of the group is real index S*E*p + f = S*n + s: s = f % S, n = E*p + f / S
 #pragma unroll
-            for (int e = 0; e < E; ++e) {
-                const int i = q * E + e;          // real index in the row: i = S*n + s, n = 2*n2 + part
-                const int n = i / S, s = i - n * S;
-                ldsf[2 * (sub_base(g * S + s, S) + (n >> 1)) + (n & 1)] = vals[it][e];
+            for (int sq = 0; sq < S; ++sq) {
+                float4* dst = reinterpret_cast<float4*>(lds + sub_base(g * S + sq, S) + (E / 2) * p);
+#pragma unroll
+                for (int h = 0; h < E / 4; ++h) {
+                    float o[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        constexpr int dummy = 0;
+                        const int f = (4 * h + a) * S + sq;   // n - E*p = 4h + a
+                        o[a] = vals[it][f / E][f % E];
+                        (void)dummy;
+                    }
+                    dst[h] = make_float4(o[0], o[1], o[2], o[3]);
+                }
             }
         }
     }
@@ -116,30 +130,47 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     split_passes(lds, tid, S, tw15);
     __syncthreads();
 
+    // mode split + radix-S combine, modes m and 240 - m together (they share Z[m], Z[240 - m]):
+    //   F[m]     = e - i p,  F[240-m] = conj(e) - i conj(p),  e = (a + conj b)/2, p = w_m (a - conj b)/2
+    //   X[m]     = sum_s W^{s m} F_s[m],   X[240-m] = sum_s conj(W^{s m}) e^{-i pi s/S} F_s[240-m]
     const float2* tw2 = tw + HH;  // exp(-2 pi i m / N)
-    for (int idx = tid; idx < G * M; idx += STHREADS) {
-        const int m = idx / G, g = idx - m * G;
+    constexpr int NPAIR = SH / 2 + 1;  // mp = 0 .. 120
+    for (int idx = tid; idx < G * NPAIR; idx += STHREADS) {
+        const int mp = idx / G, g = idx - mp * G;
         const int bc = bc0 + g;
         if (bc >= BC) continue;
-        const int i0 = (m == SH) ? 0 : m;
-        const int i1 = (m == 0 || m == SH) ? 0 : SH - m;
-        const int p0 = phi(i0), p1 = phi(i1);
-        const float2 wsub = tw2[S * m];  // exp(-2 pi i m / 480)
-        float2 acc = make_float2(0.f, 0.f);
+        const int m1 = SH - mp;                 // partner mode (240 for mp = 0)
+        const int p0 = phi(mp), p1 = phi(mp == 0 ? 0 : m1);
+        const float2 wsub = tw2[S * mp];        // exp(-2 pi i mp / 480)
+        float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const float2* zs = lds + sub_base(g * S + s, S);
             const float2 a = zs[p0];
-            float2 b = zs[p1];
-            b.y = -b.y;
-            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y + b.y));
-            const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
-            float2 f = cadd(e, mul_mi(cmul(wsub, d)));
-            if (s > 0) f = cmul(f, tw2[s * m]);
-            acc = cadd(acc, f);
+            const float2 b = zs[p1];
+            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+            const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+            const float2 pp = cmul(wsub, d);
+            float2 f0 = make_float2(e.x + pp.y, e.y - pp.x);
+            float2 f1 = make_float2(e.x - pp.y, -e.y - pp.x);
+            if (s > 0) {
+                const float2 w = tw2[s * mp];
+                constexpr float kc[3] = {1.f, 0.5f, -0.5f}, ks[3] = {0.f, -0.86602540378443864676f, -0.86602540378443864676f};
+                static_assert(S == 1 || S == 3, "combine constants are for S = 3");
+                f0 = cmul(f0, w);
+                f1 = cmul(f1, cmul(make_float2(w.x, -w.y), make_float2(kc[s], ks[s])));
+            }
+            acc0 = cadd(acc0, f0);
+            acc1 = cadd(acc1, f1);
         }
-        const float sc = (m == 0) ? scale0 : ((m == HH) ? scale_h : scale_m);
-        xf[((size_t)m * K + k) * BC + bc] = make_float2(sc * acc.x, sc * acc.y);
+        if (mp < M) {
+            const float sc = (mp == 0) ? scale0 : scale_m;
+            xf[((size_t)mp * K + k) * BC + bc] = make_float2(sc * acc0.x, sc * acc0.y);
+        }
+        if (m1 != mp && m1 < M) {
+            const float sc = (m1 == HH) ? scale_h : scale_m;
+            xf[((size_t)m1 * K + k) * BC + bc] = make_float2(sc * acc1.x, sc * acc1.y);
+        }
     }
 }
 
@@ -148,7 +179,6 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
                                                                const float2* __restrict__ tw, int BC, int K, int M,
                                                                float scale0, float scale_m, float scale_h) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2;
-    constexpr int VPR = N / 4, NV = G * VPR, IT = (NV + STHREADS - 1) / STHREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int ntile = (BC + G - 1) / G;
@@ -160,68 +190,90 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
 #pragma unroll
     for (int r = 0; r < 15; ++r) tw15[r] = tw[((tid & 15) * r) * S];
 
-    for (int idx = tid; idx < G * SH; idx += STHREADS) {
-        const int j = idx / G, g = idx - j * G;
-        const int bc = bc0 + g;
-        const int jm = SH - j;  // 1 .. 240
-        float2 xa = make_float2(0.f, 0.f), xb = make_float2(0.f, 0.f);
-        if (bc < BC) {
-            if (j < M) {
-                xa = xf[((size_t)j * K + k) * BC + bc];
-                const float sc = (j == 0) ? scale0 : scale_m;
-                xa.x *= sc;
-                xa.y *= sc;
-            }
-            if (jm < M) {
-                xb = xf[((size_t)jm * K + k) * BC + bc];
-                const float sc = (jm == HH) ? scale_h : scale_m;
-                xb.x *= sc;
-                xb.y *= sc;
-            }
+    // merge step, modes j and 240 - j together (both need X[j] and X[240 - j]):
+    //   Y_s[m] = X[m] W^{-s m};  e = Ya + conj Yb, t = w_j (Ya - conj Yb), w_j = exp(+2 pi i j / 480)
+    //   Z[j] = e + i t,  Z[240-j] = conj(e) + i conj(t); stored conjugated (inverse = conj . forward . conj)
+    constexpr int NPAIR = SH / 2 + 1;
+    constexpr int PIT = (G * NPAIR + STHREADS - 1) / STHREADS;
+    float2 xa[PIT], xb[PIT];
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        const int idx = tid + it * STHREADS;
+        const int jp = idx / G, g = idx - jp * G;
+        const int bc = bc0 + g, j1 = SH - jp;
+        xa[it] = make_float2(0.f, 0.f);
+        xb[it] = make_float2(0.f, 0.f);
+        if (idx < G * NPAIR && bc < BC) {
+            if (jp < M) xa[it] = xf[((size_t)jp * K + k) * BC + bc];
+            if (j1 < M) xb[it] = xf[((size_t)j1 * K + k) * BC + bc];
         }
-        float2 wsub = tw2[S * j];
-        wsub.y = -wsub.y;  // exp(+2 pi i j / 480)
+    }
+#pragma unroll
+    for (int it = 0; it < PIT; ++it) {
+        const int idx = tid + it * STHREADS;
+        if (idx >= G * NPAIR) continue;
+        const int jp = idx / G, g = idx - jp * G;
+        const int j1 = SH - jp;
+        const float sa = (jp == 0) ? scale0 : scale_m;
+        const float sb = (j1 == HH) ? scale_h : scale_m;
+        const float2 a0 = make_float2(sa * xa[it].x, sa * xa[it].y);
+        const float2 b0 = make_float2(sb * xb[it].x, sb * xb[it].y);
+        float2 wsub = tw2[S * jp];
+        wsub.y = -wsub.y;  // exp(+2 pi i jp / 480)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            float2 ya = xa, yb = xb;
-            if (s > 0) {  // Y_s[m] = X[m] W_N^{-s m}
-                float2 wa = tw2[s * j], wb = tw2[s * jm];
-                wa.y = -wa.y;
-                wb.y = -wb.y;
-                ya = cmul(ya, wa);
-                yb = cmul(yb, wb);
+            float2 ya = a0, yb = b0;
+            if (s > 0) {
+                constexpr float kc[3] = {1.f, 0.5f, -0.5f}, ks[3] = {0.f, 0.86602540378443864676f, 0.86602540378443864676f};
+                const float2 w = tw2[s * jp];                  // W^{s jp}
+                ya = cmul(ya, make_float2(w.x, -w.y));          // X[j]  W^{-s j}
+                yb = cmul(yb, cmul(w, make_float2(kc[s], ks[s])));  // X[j1] W^{-s (240 - j)} = X[j1] e^{+i pi s/3} W^{s j}
             }
-            if (j == 0) ya.y = 0.f;             // imaginary part of the zero mode is ignored
-            if (jm == SH) {                     // Nyquist of the 480-point sub-transform
-                yb.y = 0.f;
-                if (S > 1) yb.x *= 2.f;         // interior mode of the long transform: both conjugate halves
+            if (jp == 0) {
+                ya.y = 0.f;                 // imaginary part of the zero mode is ignored
+                yb.y = 0.f;                 // Nyquist of the 480-point sub-transform is real ...
+                if (S > 1) yb.x *= 2.f;     // ... and an interior mode of the long one: both conjugate halves
             }
-            yb.y = -yb.y;                       // conj
-            const float2 e = cadd(ya, yb), d = csub(ya, yb);
+            const float2 e = make_float2(ya.x + yb.x, ya.y - yb.y);
+            const float2 d = make_float2(ya.x - yb.x, ya.y + yb.y);
             const float2 t = cmul(wsub, d);
-            // z = e + i t, stored conjugated (inverse transform = conj . forward . conj)
-            lds[sub_base(g * S + s, S) + j] = make_float2(e.x - t.y, -(e.y + t.x));
+            float2* zs = lds + sub_base(g * S + s, S);
+            zs[jp] = make_float2(e.x - t.y, -(e.y + t.x));
+            if (jp != 0 && j1 != jp) zs[j1] = make_float2(e.x + t.y, e.y - t.x);
         }
     }
     __syncthreads();
     split_passes(lds, tid, S, tw15);
     __syncthreads();
 
-    const float* ldsf = reinterpret_cast<const float*>(lds);
+    // copy-out: groups of 4*S reals = 2 complex (4 reals) of every sub-sequence, de-conjugated
+    constexpr int GPR = N / (4 * S), NGRP = G * GPR, OIT = (NGRP + STHREADS - 1) / STHREADS;
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
+    for (int it = 0; it < OIT; ++it) {
         const int v = tid + it * STHREADS;
-        const int g = v / VPR, q = v - g * VPR;
-        if (v < NV && bc0 + g < BC) {
-            float o[4];
+        const int g = v / GPR, p = v - g * GPR;
+        if (v < NGRP && bc0 + g < BC) {
+            float r[S][4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int i = q * 4 + e;
-                const int n = i / S, s = i - n * S;
-                const float val = ldsf[2 * (sub_base(g * S + s, S) + phi(n >> 1)) + (n & 1)];
-                o[e] = (n & 1) ? -val : val;
+            for (int sq = 0; sq < S; ++sq) {
+                const float2* zs = lds + sub_base(g * S + sq, S);
+                const float2 z0 = zs[phi(2 * p)], z1 = zs[phi(2 * p + 1)];
+                r[sq][0] = z0.x;
+                r[sq][1] = -z0.y;
+                r[sq][2] = z1.x;
+                r[sq][3] = -z1.y;
             }
-            *reinterpret_cast<float4*>(x + ((size_t)(bc0 + g) * K + k) * N + q * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            float* dst = x + ((size_t)(bc0 + g) * K + k) * N + (size_t)p * 4 * S;
+#pragma unroll
+            for (int c = 0; c < S; ++c) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int f = c * 4 + e;      // real index S*4*p + f = S*n + s
+                    o[e] = r[f % S][f / S];
+                }
+                reinterpret_cast<float4*>(dst)[c] = make_float4(o[0], o[1], o[2], o[3]);
+            }
         }
     }
 }
