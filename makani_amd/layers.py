@@ -13,6 +13,51 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 
+class _PointwiseConv(torch.autograd.Function):
+    """y[b] = W @ x[b] on the NCHW field viewed as [C, H*W]; hand-written backward.
+
+    hipBLASLt runs the weight-gradient GEMM  gW = gY @ X^T  (contraction over H*W ~ 1e5..1e6,
+    output only [O x I]) on a few dozen workgroups; splitting the contraction into SPLIT batched
+    chunks (strided views, no copies) and summing the partials in fp32 fills the chip.
+    """
+    SPLIT = 32
+
+    @staticmethod
+    def forward(ctx, x3, w):
+        # x3 [B, I, P], w [O, I]; dtypes already equal (autocast handled by the caller)
+        ctx.save_for_backward(x3, w)
+        if x3.shape[0] == 1:
+            return torch.mm(w, x3[0]).unsqueeze(0)
+        return torch.bmm(w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x3, w = ctx.saved_tensors
+        B, I, P = x3.shape
+        O = w.shape[0]
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if B == 1:
+                gx = torch.mm(w.t(), gy[0]).unsqueeze(0)
+            else:
+                gx = torch.bmm(w.t().unsqueeze(0).expand(B, -1, -1), gy)
+        if ctx.needs_input_grad[1]:
+            S = _PointwiseConv.SPLIT
+            while S > 1 and P % S:
+                S //= 2
+            kc = P // S
+            # per sample: [O, S, kc] -> [S, O, kc] and [I, S, kc] -> [S, kc, I] are strided views (no copies)
+            gw32 = None
+            for bi in range(B):
+                a = gy[bi].view(O, S, kc).permute(1, 0, 2)
+                b = x3[bi].view(I, S, kc).permute(1, 2, 0)
+                part = torch.bmm(a, b).float().sum(0)
+                gw32 = part if gw32 is None else gw32 + part
+            gw = gw32.to(w.dtype)
+        return gx, gw
+
+
 class Conv1x1(nn.Conv2d):
     """``nn.Conv2d(cin, cout, 1)`` evaluated as ``W @ x.view(B, C, H*W)`` (+ bias)."""
 
@@ -20,16 +65,20 @@ class Conv1x1(nn.Conv2d):
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
     def forward(self, x):
-        if x.dim() != 4 or not x.is_contiguous():
+        if x.dim() != 4 or not x.is_contiguous() or not x.is_cuda:
             return F.conv2d(x, self.weight, self.bias)
         B, C, H, W = x.shape
         w = self.weight.view(self.out_channels, self.in_channels)
         # NOTE: torch.matmul(2-D, 3-D) folds through a transposed *copy* of the activation; mm / bmm on
         # the [C, H*W] row-major view go straight to hipBLASLt with no copy in forward or backward
-        if B == 1:
-            y = torch.mm(w, x.view(C, H * W)).view(1, self.out_channels, H * W)
+        if torch.is_autocast_enabled():
+            dt = torch.get_autocast_gpu_dtype()
+            x3, w = x.view(B, C, H * W).to(dt), w.to(dt)
         else:
-            y = torch.bmm(w.unsqueeze(0).expand(B, -1, -1), x.view(B, C, H * W))
+            x3 = x.view(B, C, H * W)
+            w = w.to(x3.dtype)
+        with torch.autocast("cuda", enabled=False):
+            y = _PointwiseConv.apply(x3, w)
         if self.bias is not None:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)
