@@ -22,6 +22,8 @@
 #include "common.h"
 #include "../../include/makani_amd.h"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -260,6 +262,8 @@ struct DeinterleaveLoader {
 // ---------------------------------------------------------------------------
 // main loop + epilogue
 // ---------------------------------------------------------------------------
+__constant__ int g_exp = 0;   // tuning experiments only (MK_GEMM_EXP); 0 in production
+
 struct Epilogue {
     float* base;       // C element (row 0, col 0) of this tile
     long long ldc;     // words between consecutive C rows
@@ -272,6 +276,8 @@ __device__ __forceinline__ void gemm_tile(const ALoad& al, const BLoad& bl, int 
     const int lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int li = lane & 31, lk = lane >> 5;
+    const bool wave_live = (__builtin_amdgcn_readfirstlane(wm0) < ep.rvalid) &&
+                           (__builtin_amdgcn_readfirstlane(wn0) < ep.cvalid);
     float* As = lds;                   // [2][A_WORDS]
     float* Bs = lds + 2 * A_WORDS;     // [2][B_WORDS]
 
@@ -295,26 +301,41 @@ __device__ __forceinline__ void gemm_tile(const ALoad& al, const BLoad& bl, int 
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = kt + 1 < nk;
-        if (more) {
+        if (more && !(g_exp & 1)) {
             al.gload(kt + 1, rA, tid);
             bl.gload(kt + 1, rB, tid);
         }
         const float* a_ = As + cur * A_WORDS + lk * ALoad::LD + wm0 + li;
         const float* b_ = Bs + cur * B_WORDS + lk * BLoad::LD + wn0 + li;
+        // ragged tiles: a wave whose 32 rows (or 64 columns) are all past the valid extent does no MFMA
+        // work (it still stages operands and meets the barriers) -> the matrix pipe only sees real rows
+        if (wave_live) {
+            // fragments of k-step ks+1 are fetched from LDS before the MFMAs of step ks issue
+            float a_c = a_[0], b_c[NT];
 #pragma unroll
-        for (int ks = 0; ks < TK / 2; ++ks) {
-            const float a = a_[(2 * ks) * ALoad::LD];
+            for (int n = 0; n < NT; ++n) b_c[n] = b_[n * 32];
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const float b = b_[(2 * ks) * BLoad::LD + n * 32];
-                acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[n], 0, 0, 0);
+            for (int ks = 0; ks < TK / 2; ++ks) {
+                float a_n = 0.f, b_n[NT];
+                if (ks + 1 < TK / 2) {
+                    a_n = a_[(2 * ks + 2) * ALoad::LD];
+#pragma unroll
+                    for (int n = 0; n < NT; ++n) b_n[n] = b_[(2 * ks + 2) * BLoad::LD + n * 32];
+                }
+                __builtin_amdgcn_sched_barrier(0);  // keep the prefetch reads ahead of this step's MFMAs
+#pragma unroll
+                for (int n = 0; n < NT; ++n) acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_c, b_c[n], acc[n], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                a_c = a_n;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) b_c[n] = b_n[n];
             }
         }
-        if (more) {
+        if (more && !(g_exp & 2)) {
             al.sstore(rA, As + (cur ^ 1) * A_WORDS, tid);
             bl.sstore(rB, Bs + (cur ^ 1) * B_WORDS, tid);
         }
-        __syncthreads();
+        if (!(g_exp & 4)) __syncthreads();
     }
     // epilogue: acc reg r -> row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
 #pragma unroll
@@ -527,8 +548,19 @@ constexpr size_t kLdsBytes = sizeof(float) * 2 * (A_WORDS + B_WORDS);
 // ---------------------------------------------------------------------------
 // C ABI
 // ---------------------------------------------------------------------------
+static void apply_exp() {
+    static int last = -1;
+    const char* e = getenv("MK_GEMM_EXP");
+    const int v = e ? atoi(e) : 0;
+    if (v != last) {
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_exp), &v, sizeof(int));
+        last = v;
+    }
+}
+
 static int legendre_launch(bool fwd, const float* src, const float* tab, float* dst, int bc, int nlat, int lmax,
                            int mmax_loc, int m_off, int mmax_glob, hipStream_t st) {
+    apply_exp();
     LegParams p;
     p.src = src;
     p.tab = tab;
@@ -584,6 +616,7 @@ extern "C" int mk_legendre_inv(const float* c, const float* tab, float* xf, int 
 
 static int dh_check(const void* a, const void* b, const void* c, int lloc, int mloc, int batch, int cin, int cout,
                     int l_off, int m_off) {
+    apply_exp();
     MK_REQUIRE(a && b && c, "null pointer");
     MK_REQUIRE(lloc > 0 && mloc > 0 && batch > 0 && cin > 0 && cout > 0, "bad sizes");
     MK_REQUIRE(l_off >= 0 && m_off >= 0, "negative shard offset");
