@@ -118,6 +118,28 @@ int mk_spec_pack(const float* c_std, float* c_prv, int bc, int lloc, int mloc, v
 int mk_spec_unpack(const float* c_prv, float* c_std, int bc, int lloc, int mloc,
                    int l_off, int m_off, void* stream);
 
+/* ---- fused pointwise ops of the FNO block (rows = B*C <= 65535, P = H*W multiple of 8) -------- */
+/* dtype: 0 = fp32, 1 = bf16 storage; arithmetic is fp32.
+ * y = gelu(x + bias[row % C]) (exact erf GELU).  Replaces the bias add of nn.Conv2d(.., 1) followed by
+ * nn.GELU in MLP / EncoderDecoder (makani/models/common/layers.py:95-99,158-206). */
+int mk_bias_gelu_fwd(const void* x, const float* bias, void* y, int dtype, int rows, int C, long long P,
+                     void* stream);
+/* gx = gy * gelu'(x + bias); gbias[c] += sum over (b, p) of gx (caller zeroes gbias; may be NULL). */
+int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy, void* gx, float* gbias, int dtype,
+                     int rows, int C, long long P, void* stream);
+/* Instance norm over each row, y = act(((x - mean) * rstd) * weight[c] + bias[c]), biased variance,
+ * act = GELU if fuse_gelu else identity.  stats[row] = (mean, rstd) is kept for the backward;
+ * workspace: 2*rows doubles (zeroed inside).  Replaces nn.InstanceNorm2d(eps=1e-6, affine=True)
+ * (+ act_layer0) of FourierNeuralOperatorBlock (makani/models/networks/sfnonet.py:239-253,375-380). */
+int mk_instnorm_fwd(const void* x, const float* weight, const float* bias, void* y, float* stats,
+                    double* workspace, int dtype, int rows, int C, long long P, float eps, int fuse_gelu,
+                    void* stream);
+/* gx of the above; on return workspace[row] = (sum g', sum g' * xhat) with g' = gy * act'(z), from which
+ * the caller forms gbias[c] = sum_b workspace[b, c, 0], gweight[c] = sum_b workspace[b, c, 1]. */
+int mk_instnorm_bwd(const void* x, const void* gy, const float* stats, const float* weight, const float* bias,
+                    void* gx, double* workspace, int dtype, int rows, int C, long long P, int fuse_gelu,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

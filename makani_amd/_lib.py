@@ -37,6 +37,12 @@ SIGNATURES = {
     "mk_dhconv_wgrad": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "mk_spec_pack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "mk_spec_unpack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_bias_gelu_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_bias_gelu_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_instnorm_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _c_float,
+                                 _c_int, _vp]),
+    "mk_instnorm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong,
+                                 _c_int, _vp]),
 }
 
 

@@ -64,24 +64,63 @@ class Conv1x1(nn.Conv2d):
     def __init__(self, in_channels, out_channels, bias=True):
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
-    def forward(self, x):
+    def forward(self, x, add_bias=True):
         if x.dim() != 4 or not x.is_contiguous() or not x.is_cuda:
-            return F.conv2d(x, self.weight, self.bias)
+            return F.conv2d(x, self.weight, self.bias if add_bias else None)
         B, C, H, W = x.shape
         w = self.weight.view(self.out_channels, self.in_channels)
         # NOTE: torch.matmul(2-D, 3-D) folds through a transposed *copy* of the activation; mm / bmm on
         # the [C, H*W] row-major view go straight to hipBLASLt with no copy in forward or backward
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_gpu_dtype()
+            dt = torch.get_autocast_dtype('cuda')
             x3, w = x.view(B, C, H * W).to(dt), w.to(dt)
         else:
             x3 = x.view(B, C, H * W)
             w = w.to(x3.dtype)
         with torch.autocast("cuda", enabled=False):
             y = _PointwiseConv.apply(x3, w)
-        if self.bias is not None:
+        if self.bias is not None and add_bias:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)
+
+
+def _is_exact_gelu(m):
+    return isinstance(m, nn.GELU) and getattr(m, "approximate", "none") == "none"
+
+
+def run_pointwise_chain(mods, x):
+    """Evaluate an ``nn.Sequential`` of 1x1 convs / activations / identities, fusing every
+    ``Conv1x1(bias) -> GELU`` pair into one HIP bias+GELU pass over the conv output."""
+    from . import ops
+    mods = list(mods)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, Conv1x1) and i + 1 < len(mods) and _is_exact_gelu(mods[i + 1]) and x.is_cuda:
+            y = m(x, add_bias=False)
+            if ops.pointwise_supported(y):
+                x = ops.bias_gelu(y, m.bias)
+            else:
+                if m.bias is not None:
+                    y = y + m.bias.to(y.dtype).view(1, -1, 1, 1)
+                x = mods[i + 1](y)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+class InstanceNorm2d(nn.InstanceNorm2d):
+    """``nn.InstanceNorm2d(affine=True, track_running_stats=False)`` as two HIP streaming passes
+    (row sums, apply), optionally with the block's GELU fused into the apply pass."""
+
+    def forward(self, x, fuse_gelu=False):
+        from . import ops
+        if self.track_running_stats or not ops.pointwise_supported(x):
+            y = super().forward(x)
+            return F.gelu(y) if fuse_gelu else y
+        return ops.instance_norm(x, self.weight, self.bias, self.eps, fuse_gelu)
 
 
 def drop_path(x, drop_prob=0.0, training=False):
@@ -133,7 +172,7 @@ class EncoderDecoder(nn.Module):
         self.fwd = nn.Sequential(*mods)
 
     def forward(self, x):
-        return self.fwd(x)
+        return run_pointwise_chain(self.fwd, x)
 
 
 class MLP(nn.Module):
@@ -179,13 +218,16 @@ class MLP(nn.Module):
             drop = nn.Identity()
         self.fwd = nn.Sequential(fc1, act, drop, fc2, drop)
 
+    def _run(self, x):
+        return run_pointwise_chain(self.fwd, x)
+
     def checkpoint_forward(self, x):
-        return checkpoint(self.fwd, x, use_reentrant=False)
+        return checkpoint(self._run, x, use_reentrant=False)
 
     def forward(self, x):
         if self.checkpointing >= 2:
             return self.checkpoint_forward(x)
-        return self.fwd(x)
+        return self._run(x)
 
 
 class RealFFT2(nn.Module):

@@ -323,3 +323,97 @@ def spec_unpack(c_prv, l_off=0, m_off=0):
 
 def dhconv(x, w, batch, l_off=0, m_off=0):
     return _Dhconv.apply(x, w, batch, l_off, m_off)
+
+
+# ----------------------------------------------------------------------------
+# fused pointwise ops of the FNO block (bias + GELU, instance norm [+ GELU])
+# ----------------------------------------------------------------------------
+def _pw_dtype(t):
+    if t.dtype == torch.float32:
+        return 0
+    if t.dtype == torch.bfloat16:
+        return 1
+    raise TypeError(f"makani_amd pointwise ops: unsupported dtype {t.dtype}")
+
+
+def pointwise_supported(x):
+    """NCHW, contiguous, on the GPU, fp32/bf16, H*W a multiple of 8, B*C <= 65535."""
+    return (x.is_cuda and x.dim() == 4 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+            and (x.shape[2] * x.shape[3]) % 8 == 0 and x.shape[0] * x.shape[1] <= 65535)
+
+
+class _BiasGelu(torch.autograd.Function):
+    """y = gelu(x + bias[c]) on [B, C, H, W] (bias may be None)."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        _need_cuda(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        bf = None if bias is None else bias.detach().float().contiguous()
+        _lib.check(_lib.load().mk_bias_gelu_fwd(x.data_ptr(), 0 if bf is None else bf.data_ptr(), y.data_ptr(),
+                                                _pw_dtype(x), B * C, C, H * W, _stream()), "mk_bias_gelu_fwd")
+        ctx.save_for_backward(x, bf if bf is not None else x.new_empty(0))
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, bf = ctx.saved_tensors
+        B, C, H, W = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        gb = torch.zeros(C, dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        _lib.check(_lib.load().mk_bias_gelu_bwd(x.data_ptr(), bf.data_ptr() if ctx.has_bias else 0, gy.data_ptr(),
+                                                gx.data_ptr(), 0 if gb is None else gb.data_ptr(), _pw_dtype(x),
+                                                B * C, C, H * W, _stream()), "mk_bias_gelu_bwd")
+        return gx, (gb.to(ctx.bias_dtype) if gb is not None else None)
+
+
+class _InstanceNorm(torch.autograd.Function):
+    """Affine instance norm over (H, W) with optional fused GELU; statistics in fp32/fp64."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, fuse_gelu):
+        _need_cuda(x)
+        B, C, H, W = x.shape
+        y = torch.empty_like(x)
+        wf = None if weight is None else weight.detach().float().contiguous()
+        bf = None if bias is None else bias.detach().float().contiguous()
+        stats = torch.empty(B * C, 2, dtype=torch.float32, device=x.device)
+        ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
+        _lib.check(_lib.load().mk_instnorm_fwd(x.data_ptr(), 0 if wf is None else wf.data_ptr(),
+                                               0 if bf is None else bf.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                               ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, float(eps), int(fuse_gelu),
+                                               _stream()), "mk_instnorm_fwd")
+        empty = x.new_empty(0, dtype=torch.float32)
+        ctx.save_for_backward(x, stats, wf if wf is not None else empty, bf if bf is not None else empty)
+        ctx.cfg = (weight is not None, bias is not None, bool(fuse_gelu),
+                   None if weight is None else weight.dtype, None if bias is None else bias.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, stats, wf, bf = ctx.saved_tensors
+        has_w, has_b, fuse, wdt, bdt = ctx.cfg
+        B, C, H, W = x.shape
+        gy = gy.contiguous()
+        gx = torch.empty_like(x)
+        ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
+        _lib.check(_lib.load().mk_instnorm_bwd(x.data_ptr(), gy.data_ptr(), stats.data_ptr(),
+                                               wf.data_ptr() if has_w else 0, bf.data_ptr() if has_b else 0,
+                                               gx.data_ptr(), ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, int(fuse),
+                                               _stream()), "mk_instnorm_bwd")
+        sums = ws.view(B, C, 2).sum(0)
+        gw = sums[:, 1].to(wdt) if has_w else None
+        gb = sums[:, 0].to(bdt) if has_b else None
+        return gx, gw, gb, None, None
+
+
+def bias_gelu(x, bias):
+    return _BiasGelu.apply(x, bias)
+
+
+def instance_norm(x, weight, bias, eps=1e-5, fuse_gelu=False):
+    return _InstanceNorm.apply(x, weight, bias, eps, fuse_gelu)

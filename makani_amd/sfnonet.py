@@ -23,7 +23,7 @@ from torch.utils.checkpoint import checkpoint
 from . import comm
 from .distributed import DistributedInverseRealSHT, DistributedRealSHT
 from .layer_norm import DistributedInstanceNorm2d
-from .layers import Conv1x1, DropPath, EncoderDecoder, InverseRealFFT2, MLP, RealFFT2
+from .layers import Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _is_exact_gelu
 from .sht import InverseRealSHT, RealSHT
 from .spectral_convolution import FactorizedSpectralConv, SpectralConv
 
@@ -114,11 +114,15 @@ class FourierNeuralOperatorBlock(nn.Module):
 
     def forward(self, x):
         x, residual = self.filter(x)
-        x = self.norm0(x)
-        if hasattr(self, "inner_skip"):
-            x = x + self.inner_skip(residual)
-        if hasattr(self, "act_layer0"):
-            x = self.act_layer0(x)
+        if (isinstance(self.norm0, InstanceNorm2d) and not hasattr(self, "inner_skip")
+                and hasattr(self, "act_layer0") and _is_exact_gelu(self.act_layer0)):
+            x = self.norm0(x, fuse_gelu=True)      # norm0 + GELU in one apply pass
+        else:
+            x = self.norm0(x)
+            if hasattr(self, "inner_skip"):
+                x = x + self.inner_skip(residual)
+            if hasattr(self, "act_layer0"):
+                x = self.act_layer0(x)
         if hasattr(self, "mlp"):
             x = self.mlp(x)
         x = self.norm1(x)
@@ -183,7 +187,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             if comm.get_size("spatial") > 1:
                 norm_layer_inp = partial(DistributedInstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True)
             else:
-                norm_layer_inp = partial(nn.InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True,
+                norm_layer_inp = partial(InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True,
                                          track_running_stats=False)
             norm_layer_out = norm_layer_mid = norm_layer_inp
         elif normalization_layer == "none":

@@ -289,3 +289,52 @@ def test_pack_unpack(dev, bc, L, M):
     assert np.array_equal(u, np.where(tril_mask(L, M), c, 0))
     u2 = ops.spec_unpack_raw(p, 3, 5).cpu().numpy()
     assert np.array_equal(u2, np.where(tril_mask(L, M, 3, 5), c, 0))
+
+
+# --------------------------------------------------------------------------- fused pointwise ops
+PW_CASES = [(2, 6, 33, 64), (1, 5, 16, 24), (3, 4, 91, 8), (1, 3, 240, 480)]
+
+
+@pytest.mark.parametrize("B,C,H,W", PW_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bias_gelu(dev, B, C, H, W, dtype):
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(B, C, H, W, generator=g).to(dtype)
+    b = torch.randn(C, generator=g)
+    gy = torch.randn(B, C, H, W, generator=g).to(dtype)
+    xd, bd = x.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    assert ops.pointwise_supported(xd)
+    y = ops.bias_gelu(xd, bd)
+    y.backward(gy.to(dev))
+    xo, bo = x.double().requires_grad_(True), b.double().requires_grad_(True)
+    yo = torch.nn.functional.gelu(xo + bo.view(1, -1, 1, 1))
+    yo.backward(gy.double())
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    assert y.dtype == dtype and rel(y.detach().float().cpu().numpy(), yo.detach().numpy()) < tol
+    assert rel(xd.grad.float().cpu().numpy(), xo.grad.numpy()) < tol
+    assert rel(bd.grad.cpu().numpy(), bo.grad.numpy()) < (1e-5 if dtype == torch.float32 else 2e-2)
+
+
+@pytest.mark.parametrize("B,C,H,W", PW_CASES)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("fuse", [False, True])
+def test_instance_norm(dev, B, C, H, W, dtype, fuse):
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(4)
+    x = (torch.randn(B, C, H, W, generator=g) * 3 + 5).to(dtype)      # mean >> 0: exercises the variance formula
+    w, b = torch.randn(C, generator=g), torch.randn(C, generator=g)
+    gy = torch.randn(B, C, H, W, generator=g).to(dtype)
+    xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
+    y = ops.instance_norm(xd, wd, bd, 1e-6, fuse)
+    y.backward(gy.to(dev))
+    xo, wo, bo = (t.double().requires_grad_(True) for t in (x, w, b))
+    yo = torch.nn.functional.instance_norm(xo, weight=wo, bias=bo, eps=1e-6)
+    if fuse:
+        yo = torch.nn.functional.gelu(yo)
+    yo.backward(gy.double())
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    assert y.dtype == dtype and rel(y.detach().float().cpu().numpy(), yo.detach().numpy()) < tol
+    assert rel(xd.grad.float().cpu().numpy(), xo.grad.numpy()) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert rel(wd.grad.cpu().numpy(), wo.grad.numpy()) < (1e-4 if dtype == torch.float32 else 3e-2)
+    assert rel(bd.grad.cpu().numpy(), bo.grad.numpy()) < (1e-4 if dtype == torch.float32 else 3e-2)
