@@ -92,7 +92,7 @@ class KernelTimer:
 
         def irfft_work(out, xf, tw, nlon, *s):
             m, k, bc = xf.shape
-            return float(k * bc * (4 * nlon + 8 * m)), "byte"
+            return float(k * bc * (out.element_size() * nlon + 8 * m)), "byte"
 
         def layout_work(out, t, *a):
             return float(2 * 8 * t.numel()), "byte"

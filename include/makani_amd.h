@@ -76,8 +76,10 @@ int mk_rfft(const void* x, int x_dtype, float* xf, const float* twiddles,
  * (1, 1, 1) is `torch.fft.irfft(x, n=nlon, dim=-1, norm="forward")` of
  * InverseRealSHT.forward (spectral_convolution.py:133,141; sfnonet.py:598): modes
  * >= mmax are zero, imaginary parts of the zero and Nyquist modes are ignored.
- * With (2 pi/nlon, pi/nlon, 2 pi/nlon) it is the adjoint of mk_rfft (backward of K1). */
-int mk_irfft(const float* xf, float* x, const float* twiddles,
+ * With (2 pi/nlon, pi/nlon, 2 pi/nlon) it is the adjoint of mk_rfft (backward of K1).
+ * x_dtype: 0 = fp32 rows out, 1 = bf16 rows out (fuses the `.to(dtype)` of
+ * spectral_convolution.py:134,146; production lengths 480 / 1440 only). */
+int mk_irfft(const float* xf, void* x, int x_dtype, const float* twiddles,
              int bc, int nlat, int nlon, int mmax, float scale0, float scale_m, float scale_h,
              void* stream);
 

@@ -29,7 +29,7 @@ SIGNATURES = {
     "mk_fft_twiddle_len": (_c_int, [_c_int]),
     "mk_fft_twiddles": (_c_int, [_c_int, _vp]),
     "mk_rfft": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _vp]),
-    "mk_irfft": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _vp]),
+    "mk_irfft": (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _vp]),
     "mk_legendre_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_legendre_inv": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_dhconv_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),

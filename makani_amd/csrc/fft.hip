@@ -496,8 +496,12 @@ extern "C" int mk_rfft(const void* x, int x_dtype, float* xf, const float* twidd
     return 0;
 }
 
-extern "C" int mk_irfft(const float* xf, float* x, const float* twiddles, int bc, int nlat, int nlon, int mmax,
-                        float scale0, float scale_m, float scale_h, void* stream) {
+extern "C" int mk_irfft(const float* xf, void* xout, int x_dtype, const float* twiddles, int bc, int nlat, int nlon,
+                        int mmax, float scale0, float scale_m, float scale_h, void* stream) {
+    float* x = (float*)xout;
+    MK_REQUIRE(x_dtype == 0 || x_dtype == 1, "x_dtype must be 0 (fp32) or 1 (bf16)");
+    MK_REQUIRE(x_dtype == 0 || (!fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440)),
+               "bf16 output rows are built for the production lengths only (nlon 480 / 1440, mmax <= 241)");
     MK_REQUIRE(x && xf && twiddles, "null pointer");
     MK_REQUIRE(bc > 0 && nlat > 0 && nlon >= 2 && nlon % 2 == 0, "bad sizes (nlon must be even)");
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "mmax out of range");
@@ -505,9 +509,9 @@ extern "C" int mk_irfft(const float* xf, float* x, const float* twiddles, int bc
     hipStream_t st = (hipStream_t)stream;
     const bool split = !fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440);
     if (split && nlon == 480) {
-        launch_irfft_split<1>(xf, x, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
+        launch_irfft_split<1>(xf, xout, x_dtype, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
     } else if (split) {
-        launch_irfft_split<3>(xf, x, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
+        launch_irfft_split<3>(xf, xout, x_dtype, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, st);
     } else
     switch (nlon / 2) {
 #define X(H, G) \

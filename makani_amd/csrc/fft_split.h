@@ -174,8 +174,25 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     }
 }
 
-template <int S>
-__global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __restrict__ xf, float* __restrict__ x,
+template <typename T> struct OutVec;
+template <> struct OutVec<float> {
+    static constexpr int E = 4;
+    static __device__ __forceinline__ void store(float* p, const float (&o)[4]) {
+        *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+};
+template <> struct OutVec<__hip_bfloat16> {
+    static constexpr int E = 8;
+    static __device__ __forceinline__ void store(__hip_bfloat16* p, const float (&o)[8]) {
+        __hip_bfloat16 h[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) h[i] = __float2bfloat16(o[i]);
+        *reinterpret_cast<uint4*>(p) = *reinterpret_cast<const uint4*>(h);
+    }
+};
+
+template <int S, typename TOut>
+__global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
                                                                float scale0, float scale_m, float scale_h) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2;
@@ -246,33 +263,36 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
     split_passes(lds, tid, S, tw15);
     __syncthreads();
 
-    // copy-out: groups of 4*S reals = 2 complex (4 reals) of every sub-sequence, de-conjugated
-    constexpr int GPR = N / (4 * S), NGRP = G * GPR, OIT = (NGRP + STHREADS - 1) / STHREADS;
+    // copy-out: groups of EO*S reals = EO reals (EO/2 complex, contiguous in the padded image) of every
+    // sub-sequence, de-conjugated; EO = 4 (fp32 rows) or 8 (bf16 rows) -> 16-byte stores
+    constexpr int EO = OutVec<TOut>::E;
+    constexpr int GPR = N / (EO * S), NGRP = G * GPR, OIT = (NGRP + STHREADS - 1) / STHREADS;
 #pragma unroll
     for (int it = 0; it < OIT; ++it) {
         const int v = tid + it * STHREADS;
         const int g = v / GPR, p = v - g * GPR;
         if (v < NGRP && bc0 + g < BC) {
-            float r[S][4];
+            float r[S][EO];
 #pragma unroll
             for (int sq = 0; sq < S; ++sq) {
-                const float2* zs = lds + sub_base(g * S + sq, S);
-                const float2 z0 = zs[phi(2 * p)], z1 = zs[phi(2 * p + 1)];
-                r[sq][0] = z0.x;
-                r[sq][1] = -z0.y;
-                r[sq][2] = z1.x;
-                r[sq][3] = -z1.y;
+                const float2* zs = lds + sub_base(g * S + sq, S) + phi((EO / 2) * p);
+#pragma unroll
+                for (int h = 0; h < EO / 2; ++h) {
+                    const float2 z = zs[h];
+                    r[sq][2 * h] = z.x;
+                    r[sq][2 * h + 1] = -z.y;
+                }
             }
-            float* dst = x + ((size_t)(bc0 + g) * K + k) * N + (size_t)p * 4 * S;
+            TOut* dst = x + ((size_t)(bc0 + g) * K + k) * N + (size_t)p * EO * S;
 #pragma unroll
             for (int c = 0; c < S; ++c) {
-                float o[4];
+                float o[EO];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int f = c * 4 + e;      // real index S*4*p + f = S*n + s
+                for (int e = 0; e < EO; ++e) {
+                    const int f = c * EO + e;      // real index S*EO*p + f = S*n + s
                     o[e] = r[f % S][f / S];
                 }
-                reinterpret_cast<float4*>(dst)[c] = make_float4(o[0], o[1], o[2], o[3]);
+                OutVec<TOut>::store(dst + c * EO, o);
             }
         }
     }
@@ -294,13 +314,17 @@ int launch_rfft_split(const void* x, int x_dtype, float* xf, const float* tw, in
 }
 
 template <int S>
-int launch_irfft_split(const float* xf, float* x, const float* tw, int bc, int nlat, int mmax, float s0, float sm,
-                       float sh, hipStream_t st) {
+int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, int bc, int nlat, int mmax, float s0,
+                       float sm, float sh, hipStream_t st) {
     constexpr int G = SNSUB / S;
     const dim3 grid((unsigned)(mk::ceil_div(bc, G) * nlat));
     const size_t lds = sizeof(float2) * SLDS_F2;
-    hipLaunchKernelGGL((irfft_split_kernel<S>), grid, dim3(STHREADS), lds, st, (const float2*)xf, x, (const float2*)tw,
-                       bc, nlat, mmax, s0, sm, sh);
+    if (x_dtype == 0)
+        hipLaunchKernelGGL((irfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (float*)x,
+                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+    else
+        hipLaunchKernelGGL((irfft_split_kernel<S, __hip_bfloat16>), grid, dim3(STHREADS), lds, st, (const float2*)xf,
+                           (__hip_bfloat16*)x, (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
     return 0;
 }
 

@@ -166,7 +166,7 @@ class DistributedInverseRealSHT(_DistSHTBase):
         super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
         self.register_buffer("pct", ops.legendre_table(grid, nlat, self.lmax, self.mmax, False), persistent=False)
 
-    def inverse_packed(self, c, B):
+    def inverse_packed(self, c, B, out_dtype=torch.float32):
         """spectrum [l_loc, m_loc, B*C] -> x [B, C, nlat_loc, nlon_loc]."""
         C = c.shape[2] // B
         c = c.view(c.shape[0], c.shape[1], B, C)
@@ -180,7 +180,7 @@ class DistributedInverseRealSHT(_DistSHTBase):
         if self.comm_size_azimuth > 1:      # make modes local, split channels over w
             xf = distributed_transpose_azimuth.apply(xf, (3, 0), self.m_shapes)
         Cw = xf.shape[3]
-        x = ops.irfft(xf.reshape(self.mmax, xf.shape[1], B * Cw).contiguous(), self.twiddles, self.nlon)
+        x = ops.irfft(xf.reshape(self.mmax, xf.shape[1], B * Cw).contiguous(), self.twiddles, self.nlon, out_dtype)
         x = x.view(B, Cw, -1, self.nlon)
         if self.comm_size_azimuth > 1:      # split longitude over w, channels local again
             x = distributed_transpose_azimuth.apply(x, (-1, 1), compute_split_shapes(C, self.comm_size_azimuth))

@@ -23,9 +23,15 @@ class _PointwiseConv(torch.autograd.Function):
     SPLIT = 32
 
     @staticmethod
-    def forward(ctx, x3, w):
-        # x3 [B, I, P], w [O, I]; dtypes already equal (autocast handled by the caller)
+    def forward(ctx, x3, w, addend):
+        # x3 [B, I, P], w [O, I], optional addend [B, O, P] (skip connection folded into the GEMM
+        # epilogue: y = addend + W x); dtypes already equal (autocast handled by the caller)
         ctx.save_for_backward(x3, w)
+        ctx.has_addend = addend is not None
+        if addend is not None:
+            if x3.shape[0] == 1:
+                return torch.addmm(addend[0], w, x3[0]).unsqueeze(0)
+            return torch.baddbmm(addend, w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
         if x3.shape[0] == 1:
             return torch.mm(w, x3[0]).unsqueeze(0)
         return torch.bmm(w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
@@ -37,6 +43,7 @@ class _PointwiseConv(torch.autograd.Function):
         O = w.shape[0]
         gy = gy.contiguous()
         gx = gw = None
+        ga = gy if ctx.has_addend else None
         if ctx.needs_input_grad[0]:
             if B == 1:
                 gx = torch.mm(w.t(), gy[0]).unsqueeze(0)
@@ -55,7 +62,7 @@ class _PointwiseConv(torch.autograd.Function):
                 part = torch.bmm(a, b).float().sum(0)
                 gw32 = part if gw32 is None else gw32 + part
             gw = gw32.to(w.dtype)
-        return gx, gw
+        return gx, gw, ga
 
 
 class Conv1x1(nn.Conv2d):
@@ -64,9 +71,11 @@ class Conv1x1(nn.Conv2d):
     def __init__(self, in_channels, out_channels, bias=True):
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
-    def forward(self, x, add_bias=True):
+    def forward(self, x, add_bias=True, addend=None):
+        """``addend`` (same shape as the output) is added inside the GEMM epilogue: y = addend + conv(x)."""
         if x.dim() != 4 or not x.is_contiguous() or not x.is_cuda:
-            return F.conv2d(x, self.weight, self.bias if add_bias else None)
+            y = F.conv2d(x, self.weight, self.bias if add_bias else None)
+            return y if addend is None else y + addend
         B, C, H, W = x.shape
         w = self.weight.view(self.out_channels, self.in_channels)
         # NOTE: torch.matmul(2-D, 3-D) folds through a transposed *copy* of the activation; mm / bmm on
@@ -78,7 +87,10 @@ class Conv1x1(nn.Conv2d):
             x3 = x.view(B, C, H * W)
             w = w.to(x3.dtype)
         with torch.autocast("cuda", enabled=False):
-            y = _PointwiseConv.apply(x3, w)
+            a3 = None
+            if addend is not None:
+                a3 = addend.contiguous().view(B, self.out_channels, H * W).to(x3.dtype)
+            y = _PointwiseConv.apply(x3, w, a3)
         if self.bias is not None and add_bias:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)
@@ -88,14 +100,25 @@ def _is_exact_gelu(m):
     return isinstance(m, nn.GELU) and getattr(m, "approximate", "none") == "none"
 
 
-def run_pointwise_chain(mods, x):
+def run_pointwise_chain(mods, x, skip_last_bias=False):
     """Evaluate an ``nn.Sequential`` of 1x1 convs / activations / identities, fusing every
-    ``Conv1x1(bias) -> GELU`` pair into one HIP bias+GELU pass over the conv output."""
+    ``Conv1x1(bias) -> GELU`` pair into one HIP bias+GELU pass over the conv output.
+
+    ``skip_last_bias``: the caller feeds the result straight into an instance norm, which removes any
+    per-channel constant -- the last conv's bias add is then a no-op on the output (and its gradient is
+    identically zero), so the pass over the tensor is skipped.
+    """
     from . import ops
     mods = list(mods)
+    last_conv = max((j for j, m in enumerate(mods) if isinstance(m, Conv1x1)), default=-1)
+    tail_is_identity = all(isinstance(m, nn.Identity) for m in mods[last_conv + 1:])
     i = 0
     while i < len(mods):
         m = mods[i]
+        if skip_last_bias and tail_is_identity and i == last_conv and x.is_cuda:
+            x = m(x, add_bias=False)
+            i += 1
+            continue
         if isinstance(m, Conv1x1) and i + 1 < len(mods) and _is_exact_gelu(mods[i + 1]) and x.is_cuda:
             y = m(x, add_bias=False)
             if ops.pointwise_supported(y):
@@ -218,16 +241,16 @@ class MLP(nn.Module):
             drop = nn.Identity()
         self.fwd = nn.Sequential(fc1, act, drop, fc2, drop)
 
-    def _run(self, x):
-        return run_pointwise_chain(self.fwd, x)
+    def _run(self, x, skip_last_bias=False):
+        return run_pointwise_chain(self.fwd, x, skip_last_bias)
 
-    def checkpoint_forward(self, x):
-        return checkpoint(self._run, x, use_reentrant=False)
+    def checkpoint_forward(self, x, skip_last_bias=False):
+        return checkpoint(self._run, x, skip_last_bias, use_reentrant=False)
 
-    def forward(self, x):
+    def forward(self, x, skip_last_bias=False):
         if self.checkpointing >= 2:
-            return self.checkpoint_forward(x)
-        return self._run(x)
+            return self.checkpoint_forward(x, skip_last_bias)
+        return self._run(x, skip_last_bias)
 
 
 class RealFFT2(nn.Module):

@@ -86,15 +86,21 @@ def rfft_raw(x, twiddles, mmax, s0, sm, sh):
     return xf
 
 
-def irfft_raw(xf, twiddles, nlon, s0, sm, sh):
-    """xf complex64 [M, K, BC] -> x fp32 [BC, K, nlon]."""
+def irfft_bf16_rows(nlon, mmax):
+    """bf16 output rows are built for the production lengths (the split kernels) only."""
+    return nlon in (480, 1440) and mmax <= 241
+
+
+def irfft_raw(xf, twiddles, nlon, s0, sm, sh, out_dtype=torch.float32):
+    """xf complex64 [M, K, BC] -> x [BC, K, nlon] in fp32, or bf16 where the kernel fuses the cast."""
     _need_cuda(xf, twiddles)
     assert xf.dim() == 3 and xf.is_contiguous() and xf.dtype == torch.complex64
     m, k, bc = xf.shape
-    x = torch.empty(bc, k, nlon, dtype=torch.float32, device=xf.device)
-    _lib.check(_lib.load().mk_irfft(xf.data_ptr(), x.data_ptr(), twiddles.data_ptr(), bc, k, nlon, m,
+    fused = out_dtype == torch.bfloat16 and irfft_bf16_rows(nlon, m)
+    x = torch.empty(bc, k, nlon, dtype=torch.bfloat16 if fused else torch.float32, device=xf.device)
+    _lib.check(_lib.load().mk_irfft(xf.data_ptr(), x.data_ptr(), 1 if fused else 0, twiddles.data_ptr(), bc, k, nlon, m,
                                     s0, sm, sh, _stream()), "mk_irfft")
-    return x
+    return x if x.dtype == out_dtype else x.to(out_dtype)
 
 
 def legendre_fwd_raw(xf, table, lmax, m_off=0):
@@ -203,23 +209,25 @@ class _RFFT(torch.autograd.Function):
     def backward(ctx, gxf):
         (tw,) = ctx.saved_tensors
         n = ctx.nlon
-        gx = irfft_raw(gxf.contiguous(), tw, n, 2.0 * math.pi / n, math.pi / n, 2.0 * math.pi / n)
-        return gx.to(ctx.in_dtype), None, None
+        gx = irfft_raw(gxf.contiguous(), tw, n, 2.0 * math.pi / n, math.pi / n, 2.0 * math.pi / n, ctx.in_dtype)
+        return gx, None, None
 
 
 class _IRFFT(torch.autograd.Function):
     """xf [M, K, BC] -> x [BC, K, nlon] = irfft(xf, n=nlon, norm="forward") (K4)."""
 
     @staticmethod
-    def forward(ctx, xf, twiddles, nlon):
+    def forward(ctx, xf, twiddles, nlon, out_dtype):
         ctx.save_for_backward(twiddles)
         ctx.mmax = xf.shape[0]
-        return irfft_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0)
+        return irfft_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0, out_dtype)
 
     @staticmethod
     def backward(ctx, gx):
         (tw,) = ctx.saved_tensors
-        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0), None, None
+        if gx.dtype not in (torch.float32, torch.bfloat16):
+            gx = gx.float()
+        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0), None, None, None
 
 
 class _LegendreFwd(torch.autograd.Function):
@@ -301,8 +309,8 @@ def rfft(x, twiddles, mmax):
     return _RFFT.apply(x, twiddles, mmax)
 
 
-def irfft(xf, twiddles, nlon):
-    return _IRFFT.apply(xf, twiddles, nlon)
+def irfft(xf, twiddles, nlon, out_dtype=torch.float32):
+    return _IRFFT.apply(xf, twiddles, nlon, out_dtype)
 
 
 def legendre_fwd(xf, table, lmax, m_off=0):

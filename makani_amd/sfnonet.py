@@ -123,12 +123,17 @@ class FourierNeuralOperatorBlock(nn.Module):
                 x = x + self.inner_skip(residual)
             if hasattr(self, "act_layer0"):
                 x = self.act_layer0(x)
+        norm1_is_instance = isinstance(self.norm1, (nn.InstanceNorm2d, DistributedInstanceNorm2d))
         if hasattr(self, "mlp"):
-            x = self.mlp(x)
+            # a per-channel bias in front of an instance norm cancels exactly: skip that pass
+            x = self.mlp(x, skip_last_bias=norm1_is_instance)
         x = self.norm1(x)
         x = self.drop_path(x)
         if hasattr(self, "outer_skip"):
-            x = x + self.outer_skip(residual)
+            if isinstance(self.outer_skip, Conv1x1):
+                x = self.outer_skip(residual, addend=x)   # skip add folded into the GEMM epilogue
+            else:
+                x = x + self.outer_skip(residual)
         if hasattr(self, "act_layer1"):
             x = self.act_layer1(x)
         return x

@@ -77,10 +77,10 @@ class InverseRealSHT(_SHTBase):
         super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
         self.register_buffer("pct", ops.legendre_table(grid, nlat, self.lmax, self.mmax, False), persistent=False)
 
-    def inverse_packed(self, c):
-        """spectrum [lmax, mmax, BC] -> x [BC, nlat, nlon] fp32."""
+    def inverse_packed(self, c, out_dtype=torch.float32):
+        """spectrum [lmax, mmax, BC] -> x [BC, nlat, nlon] (fp32, or bf16 rows straight from the FFT kernel)."""
         xf = ops.legendre_inv(c, self.pct, self.nlat, 0)
-        return ops.irfft(xf, self.twiddles, self.nlon)
+        return ops.irfft(xf, self.twiddles, self.nlon, out_dtype)
 
     def forward(self, x):
         if x.shape[-2] != self.lmax or x.shape[-1] != self.mmax:

@@ -120,12 +120,14 @@ class SpectralConv(nn.Module):
             c = ft.forward_packed(xin)
         else:
             c = ft.forward_packed(xin.view(B * C, xin.shape[2], xin.shape[3]))
+        # the inverse FFT writes its rows directly in the layer's activation dtype (fp32, or bf16 under AMP)
+        odt = dtype if dtype in (torch.float32, torch.bfloat16) else torch.float32
         residual = x
         if self.scale_residual:
-            r = it.inverse_packed(c, B) if self._distributed else it.inverse_packed(c)
+            r = it.inverse_packed(c, B, odt) if self._distributed else it.inverse_packed(c, odt)
             residual = r.view(B, C, r.shape[-2], r.shape[-1]).to(dtype)
         y = ops.dhconv(c, self._weight_tensor(), B, self.l_off, self.m_off)
-        out = it.inverse_packed(y, B) if self._distributed else it.inverse_packed(y)
+        out = it.inverse_packed(y, B, odt) if self._distributed else it.inverse_packed(y, odt)
         out = out.view(B, self.out_channels, out.shape[-2], out.shape[-1])
         return out, residual
 

@@ -37,8 +37,8 @@ def _install_cpu_ops():
         y = 2.0 * math.pi * torch.fft.rfft(x.float(), dim=-1, norm="forward")[..., :mmax]
         return y.permute(2, 1, 0).contiguous()
 
-    def irfft(xf, tw, nlon):
-        return torch.fft.irfft(xf.permute(2, 1, 0), n=nlon, dim=-1, norm="forward").contiguous()
+    def irfft(xf, tw, nlon, out_dtype=torch.float32):
+        return torch.fft.irfft(xf.permute(2, 1, 0), n=nlon, dim=-1, norm="forward").contiguous().to(out_dtype)
 
     def legendre_fwd(xf, table, lmax, m_off=0):
         mloc, k, _ = xf.shape

@@ -122,7 +122,9 @@ def test_sfno_net_vs_oracle(dev, kw):
     # some gradients vanish analytically (a bias in front of an instance norm): measure every parameter's
     # error against the typical gradient norm instead of its own ~0 norm
     scale = float(np.median([torch.linalg.norm(_f64(p.grad)).item() for p in po.values()]))
-    errs = {n: rel(p.grad, po[n].grad, floor=1e-1 * scale) for n, p in net.named_parameters()}
+    # a bias in front of an instance norm has an identically zero gradient; the fused path skips that add (grad None)
+    errs = {n: rel(p.grad if p.grad is not None else torch.zeros_like(p), po[n].grad, floor=1e-1 * scale)
+            for n, p in net.named_parameters()}
     worst = max(errs, key=errs.get)
     assert errs[worst] < 5 * TOL, (worst, errs[worst])
 
@@ -140,4 +142,4 @@ def test_sfno_bf16_autocast_runs_and_is_close(dev):
         y = net(x.to(dev))
     y.float().sum().backward()
     assert rel(y.float(), ref(x)) < 3e-2
-    assert all(p.grad is not None for p in net.parameters())
+    assert all(p.grad is not None for n, p in net.named_parameters() if not n.endswith("mlp.fwd.3.bias"))
