@@ -131,6 +131,21 @@ class KernelTimer:
 # ----------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a port of the reference formulation) on the host cores
 # ----------------------------------------------------------------------------------------
+def _measured_traffic(kernel):
+    """HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, rocprofv3 passes of this same command,
+    summarised by tools/traffic_summary.py into profiles/rNN_traffic.json); None if not profiled."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        k = json.load(open(files[-1]))["kernels"].get(kernel)
+        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "unit": "B",
+                                       "source": os.path.relpath(files[-1], ROOT)}
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def _host_cores():
     """Threads for the CPU leg: the cgroup CPU quota if there is one, else the affinity mask,
     never more than 16 (a 1-GPU box's host share; its affinity mask shows the whole machine)."""
@@ -295,7 +310,7 @@ def main():
             dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
             k = kernels[dom]
             roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
-                    "frac": k["frac"], "traffic": None, "avg_launch_ms": k["avg_launch_ms"]}
+                    "frac": k["frac"], "traffic": _measured_traffic(dom), "avg_launch_ms": k["avg_launch_ms"]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()

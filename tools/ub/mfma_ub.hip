@@ -65,7 +65,13 @@ void run(const char* name, int wgs, int lds, int iters) {
 }
 
 int main() {
-    run<2, 2>("short WGs: 24 iters, 3456 wgs", 3456, 49920, 24);
+    run<2, 2>("short 24it 3456wg lds 49920", 3456, 49920, 24);
+    run<2, 2>("short 24it 3456wg lds 32768", 3456, 32768+4096, 24);
+    run<2, 2>("short 24it 6912wg lds 49920", 6912, 49920, 24);
+    run<2, 2>("short 12it 6912wg lds 49920", 6912, 49920, 12);
+    run<2, 2>("short 48it 1728wg lds 49920", 1728, 49920, 48);
+    run<2, 2>("short 240it 768wg lds 49920", 768, 49920, 240);
+    run<2, 2>("short 24it 3456wg lds 65536", 3456, 65536+8192, 24);
     run<2, 2>("short WGs: 24 iters, 768 wgs", 768, 49920, 24);
     run<2, 2>("short WGs: 96 iters, 3456 wgs", 3456, 49920, 96);
     run<2, 2>("short WGs: 24 iters, 34560 wgs", 34560, 49920, 24);
