@@ -140,8 +140,7 @@ def _measured_traffic(kernel):
         return None
     try:
         k = json.load(open(files[-1]))["kernels"].get(kernel)
-        return None if k is None else {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "unit": "B",
-                                       "source": os.path.relpath(files[-1], ROOT)}
+        return None if k is None else k["hbm_bytes_per_launch"]
     except (OSError, ValueError, KeyError):
         return None
 
@@ -310,7 +309,8 @@ def main():
             dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
             k = kernels[dom]
             roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
-                    "frac": k["frac"], "traffic": _measured_traffic(dom), "avg_launch_ms": k["avg_launch_ms"]}
+                    "frac": k["frac"], "traffic": _measured_traffic(dom), "traffic_unit": "HBM bytes per launch (PMC)",
+                    "avg_launch_ms": k["avg_launch_ms"]}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
