@@ -234,6 +234,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture forward+loss+backward in a HIP graph and replay it (reference: trainer.py:84-152, "
+                         "optimizer step outside the graph); kernel timing then comes from an eager pre-pass")
     args = ap.parse_args()
 
     from makani_amd import comm, mappings
@@ -283,13 +286,42 @@ def main():
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
+
+    timed_step = step
+    pre_kernels = None
+    if args.graph:
+        if not args.no_kernel_timing:       # events cannot be recorded inside a captured graph
+            timer.enabled = True
+            for _ in range(2):
+                step()
+            torch.cuda.synchronize()
+            timer.enabled = False
+            pre_kernels = timer.summary(2)
+            timer.records.clear()
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        static_loss = None
+        with torch.cuda.graph(graph):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = net(inp)
+            static_loss = (((pred.float() - tar) ** 2) * wq).sum() / (B * 73)
+            static_loss.backward()
+
+        def timed_step():
+            graph.replay()
+            mappings.reduce_shared_gradients(net)
+            opt.step()
+            return static_loss
+        timed_step()
+        torch.cuda.synchronize()
+
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    timer.enabled = not args.no_kernel_timing
+    timer.enabled = not args.no_kernel_timing and not args.graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = timed_step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -304,6 +336,8 @@ def main():
 
     if rank == 0:
         kernels = timer.summary(args.steps) if not args.no_kernel_timing else {}
+        if pre_kernels is not None:
+            kernels = pre_kernels
         roof = None
         if kernels:
             dom = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
@@ -320,7 +354,8 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "sfno_linear_73chq_sc3_layers8_edim384 fwd+bwd+Adam, 73ch 721x1440, per-GPU batch 1",
-                       "global_batch": B, "parallelism": f"h{hsize}", "spectral_dtype": "f32"},
+                       "global_batch": B, "parallelism": f"h{hsize}", "spectral_dtype": "f32",
+                       "step_launch": "hipGraph replay" if args.graph else "eager"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels, "loss": round(loss.item(), 6),
         }
         print(json.dumps(line), flush=True)

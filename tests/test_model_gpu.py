@@ -143,3 +143,44 @@ def test_sfno_bf16_autocast_runs_and_is_close(dev):
     y.float().sum().backward()
     assert rel(y.float(), ref(x)) < 3e-2
     assert all(p.grad is not None for n, p in net.named_parameters() if not n.endswith("mlp.fwd.3.bias"))
+
+
+def test_hip_graph_capture_replay(dev):
+    """The step is capturable in a HIP graph (reference: trainer.py:84-152): every launch goes to the
+    capturing stream, nothing allocates with hipMalloc or synchronises; replays reproduce the eager result."""
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    torch.manual_seed(7)
+    kw = dict(inp_shape=(32, 64), out_shape=(32, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=8, num_layers=2)
+    net = SphericalFourierNeuralOperatorNet(**kw).to(dev)
+    x = torch.randn(2, 4, 32, 64, device=dev)
+    tar = torch.randn(2, 3, 32, 64, device=dev)
+
+    def fb():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x)
+        loss = ((y.float() - tar) ** 2).mean()
+        loss.backward()
+        return loss
+
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            net.zero_grad(set_to_none=True)
+            fb()
+    torch.cuda.current_stream().wait_stream(s)
+    net.zero_grad(set_to_none=True)
+    ref_loss = fb()
+    ref_grads = {n: p.grad.clone() for n, p in net.named_parameters() if p.grad is not None}
+    net.zero_grad(set_to_none=True)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        loss = fb()
+    for _ in range(2):
+        x.copy_(x)          # static input (same values): replay must reproduce the eager numbers
+        g.replay()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref_loss.item()) <= 1e-6 * abs(ref_loss.item())
+    for n, p in net.named_parameters():
+        if n in ref_grads:
+            assert torch.equal(p.grad, ref_grads[n]) or rel(p.grad, ref_grads[n]) < 1e-5, n
