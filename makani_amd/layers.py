@@ -20,7 +20,7 @@ class _PointwiseConv(torch.autograd.Function):
     output only [O x I]) on a few dozen workgroups; splitting the contraction into SPLIT batched
     chunks (strided views, no copies) and summing the partials in fp32 fills the chip.
     """
-    SPLIT = 32
+    SPLIT = int(__import__("os").environ.get("MK_WGRAD_SPLIT", "32"))
 
     @staticmethod
     def forward(ctx, x3, w, addend):
