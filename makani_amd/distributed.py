@@ -51,8 +51,13 @@ def _transpose(x, dim0, dim1, dim1_split_sizes, group):
     dim1 %= x.dim()
     dim0_split_sizes = compute_split_shapes(x.shape[dim0], size)
     chunks = torch.split(x, dim0_split_sizes, dim=dim0)
-    send = torch.cat([c.reshape(-1) for c in chunks])
     in_splits = [c.numel() for c in chunks]
+    # pack: ONE strided copy per peer straight into the contiguous send buffer
+    send = torch.empty(sum(in_splits), dtype=x.dtype, device=x.device)
+    off = 0
+    for c, n in zip(chunks, in_splits):
+        send[off:off + n].view(c.shape).copy_(c)
+        off += n
     shp = list(chunks[rank].shape)
     out_shapes = []
     for s in dim1_split_sizes:
