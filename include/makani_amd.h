@@ -142,6 +142,13 @@ int mk_instnorm_bwd(const void* x, const void* gy, const float* stats, const flo
                     void* gx, double* workspace, int dtype, int rows, int C, long long P, int fuse_gelu,
                     void* stream);
 
+/* ---- 1x1 convolution weight gradient (bf16 MFMA) ------------------------------------------ */
+/* gw[o][i] += sum over (b, p) of gy[b][o][p] * x[b][i][p]; gy, x bf16 [B][C][P] (P multiple of 8), gw fp32
+ * [cout][cin] accumulated with atomics (caller zeroes it).  The weight gradient of nn.Conv2d(cin, cout, 1)
+ * in MLP / EncoderDecoder / skip connections (layers.py:95-128,158-183; sfnonet.py:207,463). */
+int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,173 @@
+// bf16 MFMA kernels for the 1x1 convolutions of the FNO block / encoder / decoder on NCHW fields
+// viewed as [C][P = H*W] (the pointwise stack between the spectral ops).
+//
+// mk_conv1x1_wgrad:  gW[o][i] += sum_p gY[o][p] * X[i][p]    (contraction over the ~1e5..1e6 pixels)
+//
+// Both operands are contiguous along the contraction index p, which is exactly the fragment shape of
+// v_mfma_f32_32x32x16_bf16 (lane (r, h) holds 8 consecutive k of row r): tiles are staged with plain
+// 16-byte loads / ds_write_b128 into rows padded to 144 bytes (conflict-free ds_read_b128), no
+// transposed reads.  A workgroup owns a 128 x 128 block of gW and a slab of pixels; the slabs are
+// combined with fp32 atomics (shaped as 128-byte row segments).  All blocks of one pixel slab are dealt
+// to the same XCD so the slab is read from HBM once and re-read from that XCD's L2.
+#include "common.h"
+#include "../../include/makani_amd.h"
+
+#include <hip/hip_bf16.h>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int WT = 256;          // threads (4 waves, 2 x 2)
+constexpr int WTO = 128, WTI = 128, WTK = 64;
+constexpr int WPITCH = WTK * 2 + 16;          // bytes per LDS row: 128 data + 16 pad
+constexpr int WTILE_BYTES = WTO * WPITCH;     // one operand tile (128 rows)
+
+struct WgradParams {
+    const __hip_bfloat16* gy;   // [B][O][P]
+    const __hip_bfloat16* x;    // [B][I][P]
+    float* gw;                  // [O][I], accumulated
+    int O, I, B;
+    long long P;
+    int nblk_o, nblk_i, nslab;  // nslab slabs per batch item
+    int slab;                   // pixels per slab (multiple of 64)
+};
+
+// 128 rows x 64 k bf16 tile: 1024 16-byte vectors, 4 per thread
+__device__ __forceinline__ void wg_load(const __hip_bfloat16* base, long long ld, int rows_valid, long long k0,
+                                        long long kend, uint4 (&r)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = tid + i * WT;
+        const int row = v >> 3, c = v & 7;
+        const long long k = k0 + c * 8;
+        r[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (row < rows_valid && k < kend) r[i] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
+    }
+}
+__device__ __forceinline__ void wg_store(char* lds, const uint4 (&r)[4], int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int v = tid + i * WT;
+        const int row = v >> 3, c = v & 7;
+        *reinterpret_cast<uint4*>(lds + row * WPITCH + c * 16) = r[i];
+    }
+}
+
+__global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];   // [2 buffers][A tile | B tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // block -> (slab, o-block, i-block); all blocks of a slab share blockIdx % 8 (one XCD)
+    const int nblk = p.nblk_o * p.nblk_i;
+    const long long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long long seq = bid >> 3;
+    const long long slab_lin = (seq / nblk) * 8 + xcd;
+    const int blk = (int)(seq % nblk);
+    const long long nslab_tot = (long long)p.nslab * p.B;
+    if (slab_lin >= nslab_tot) return;
+    const int b = (int)(slab_lin / p.nslab);
+    const long long k_begin = (slab_lin % p.nslab) * p.slab;
+    const long long k_end = (k_begin + p.slab < p.P) ? k_begin + p.slab : p.P;
+    const int o0 = (blk / p.nblk_i) * WTO, i0 = (blk % p.nblk_i) * WTI;
+    const __hip_bfloat16* ga = p.gy + ((long long)b * p.O + o0) * p.P;
+    const __hip_bfloat16* gb = p.x + ((long long)b * p.I + i0) * p.P;
+    const int ov = p.O - o0, iv = p.I - i0;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    uint4 ra[4], rb[4];
+    const int nk = (int)((k_end - k_begin + WTK - 1) / WTK);
+    wg_load(ga, p.P, ov, k_begin, k_end, ra, tid);
+    wg_load(gb, p.P, iv, k_begin, k_end, rb, tid);
+    wg_store(lds, ra, tid);
+    wg_store(lds + WTILE_BYTES, rb, tid);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const long long k0 = k_begin + (long long)(kt + 1) * WTK;
+            wg_load(ga, p.P, ov, k0, k_end, ra, tid);
+            wg_load(gb, p.P, iv, k0, k_end, rb, tid);
+        }
+        const char* As = lds + cur * 2 * WTILE_BYTES;
+        const char* Bs = As + WTILE_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < WTK / 16; ++ks) {
+            bf16x8 af[2], bf[2];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+                af[a] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + a * 32 + fr) * WPITCH + ks * 32 + fh * 16);
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+                bf[c] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + c * 32 + fr) * WPITCH + ks * 32 + fh * 16);
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int c = 0; c < 2; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            wg_store(lds + (cur ^ 1) * 2 * WTILE_BYTES, ra, tid);
+            wg_store(lds + (cur ^ 1) * 2 * WTILE_BYTES + WTILE_BYTES, rb, tid);
+        }
+        __syncthreads();
+    }
+    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); rows = o, cols = i
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int col = i0 + wc * 64 + c * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = o0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < p.O && col < p.I) atomicAdd(&p.gw[(long long)row * p.I + col], acc[a][c][r]);
+            }
+        }
+}
+
+
+}  // namespace
+
+extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
+                                void* stream) {
+    MK_REQUIRE(gy && x && gw, "null pointer");
+    MK_REQUIRE(batch > 0 && cout > 0 && cin > 0 && P > 0, "bad sizes");
+    MK_REQUIRE((P % 8) == 0, "P = H*W must be a multiple of 8 (16-byte row alignment)");
+    WgradParams p;
+    p.gy = (const __hip_bfloat16*)gy;
+    p.x = (const __hip_bfloat16*)x;
+    p.gw = gw;
+    p.O = cout;
+    p.I = cin;
+    p.B = batch;
+    p.P = P;
+    p.nblk_o = mk::ceil_div(cout, WTO);
+    p.nblk_i = mk::ceil_div(cin, WTI);
+    // slab length: enough workgroups to fill the chip (>= ~1500), at least 512 pixels each
+    {
+        const long long nblk = (long long)p.nblk_o * p.nblk_i * batch;
+        long long want = (1536 + nblk - 1) / nblk;              // slabs per batch item
+        long long slab = (P + want - 1) / want;
+        slab = (slab + 63) / 64 * 64;
+        if (slab < 512) slab = 512;
+        p.slab = (int)slab;
+    }
+    p.nslab = (int)((P + p.slab - 1) / p.slab);
+    const long long nslab_tot = (long long)p.nslab * batch;
+    const long long grid = ((nslab_tot + 7) / 8) * 8 * p.nblk_o * p.nblk_i;
+    MK_REQUIRE(grid < 2147483647LL, "grid too large");
+    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3((unsigned)grid), dim3(WT), 4 * WTILE_BYTES, (hipStream_t)stream, p);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
