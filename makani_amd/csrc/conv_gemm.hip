@@ -13,6 +13,7 @@
 #include "../../include/makani_amd.h"
 
 #include <hip/hip_bf16.h>
+#include <cstdlib>
 
 namespace {
 
@@ -20,9 +21,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WT = 256;          // threads (4 waves, 2 x 2)
-constexpr int WTO = 128, WTI = 128, WTK = 64;
+constexpr int WTI = 128, WTK = 64;            // workgroup tile: (64 * MT) o  x  128 i, k-step 64
 constexpr int WPITCH = WTK * 2 + 16;          // bytes per LDS row: 128 data + 16 pad
-constexpr int WTILE_BYTES = WTO * WPITCH;     // one operand tile (128 rows)
+constexpr int WTILE_BYTES = WTI * WPITCH;     // a 128-row operand tile
+static int wgrad_target() { static int v = [] { const char* e = getenv("MK_WGRAD_TARGET"); return e ? atoi(e) : 1536; }(); return v; }
+#define MK_WGRAD_TARGET wgrad_target()
 
 struct WgradParams {
     const __hip_bfloat16* gy;   // [B][O][P]
@@ -34,11 +37,12 @@ struct WgradParams {
     int slab;                   // pixels per slab (multiple of 64)
 };
 
-// 128 rows x 64 k bf16 tile: 1024 16-byte vectors, 4 per thread
+// (128 * NV / 4) rows x 64 k bf16 tile: NV 16-byte vectors per thread
+template <int NV>
 __device__ __forceinline__ void wg_load(const __hip_bfloat16* base, long long ld, int rows_valid, long long k0,
-                                        long long kend, uint4 (&r)[4], int tid) {
+                                        long long kend, uint4 (&r)[NV], int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int v = tid + i * WT;
         const int row = v >> 3, c = v & 7;
         const long long k = k0 + c * 8;
@@ -46,16 +50,19 @@ __device__ __forceinline__ void wg_load(const __hip_bfloat16* base, long long ld
         if (row < rows_valid && k < kend) r[i] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
     }
 }
-__device__ __forceinline__ void wg_store(char* lds, const uint4 (&r)[4], int tid) {
+template <int NV>
+__device__ __forceinline__ void wg_store(char* lds, const uint4 (&r)[NV], int tid) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int v = tid + i * WT;
         const int row = v >> 3, c = v & 7;
         *reinterpret_cast<uint4*>(lds + row * WPITCH + c * 16) = r[i];
     }
 }
 
+template <int MT>   // 32-row o-tiles per wave: workgroup tile (64 * MT) x 128
 __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
+    constexpr int WTO = 64 * MT, ATILE = WTO * WPITCH, BUF = ATILE + WTILE_BYTES, NVA = 2 * MT;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -76,61 +83,61 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
     const __hip_bfloat16* gb = p.x + ((long long)b * p.I + i0) * p.P;
     const int ov = p.O - o0, iv = p.I - i0;
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    uint4 ra[4], rb[4];
+    uint4 ra[NVA], rb[4];
     const int nk = (int)((k_end - k_begin + WTK - 1) / WTK);
-    wg_load(ga, p.P, ov, k_begin, k_end, ra, tid);
-    wg_load(gb, p.P, iv, k_begin, k_end, rb, tid);
-    wg_store(lds, ra, tid);
-    wg_store(lds + WTILE_BYTES, rb, tid);
+    wg_load<NVA>(ga, p.P, ov, k_begin, k_end, ra, tid);
+    wg_load<4>(gb, p.P, iv, k_begin, k_end, rb, tid);
+    wg_store<NVA>(lds, ra, tid);
+    wg_store<4>(lds + ATILE, rb, tid);
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             const long long k0 = k_begin + (long long)(kt + 1) * WTK;
-            wg_load(ga, p.P, ov, k0, k_end, ra, tid);
-            wg_load(gb, p.P, iv, k0, k_end, rb, tid);
+            wg_load<NVA>(ga, p.P, ov, k0, k_end, ra, tid);
+            wg_load<4>(gb, p.P, iv, k0, k_end, rb, tid);
         }
-        const char* As = lds + cur * 2 * WTILE_BYTES;
-        const char* Bs = As + WTILE_BYTES;
+        const char* As = lds + cur * BUF;
+        const char* Bs = As + ATILE;
 #pragma unroll
         for (int ks = 0; ks < WTK / 16; ++ks) {
-            bf16x8 af[2], bf[2];
+            bf16x8 af[MT], bf[2];
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
-                af[a] = *reinterpret_cast<const bf16x8*>(As + (wr * 64 + a * 32 + fr) * WPITCH + ks * 32 + fh * 16);
+            for (int a = 0; a < MT; ++a)
+                af[a] = *reinterpret_cast<const bf16x8*>(As + (wr * 32 * MT + a * 32 + fr) * WPITCH + ks * 32 + fh * 16);
 #pragma unroll
             for (int c = 0; c < 2; ++c)
                 bf[c] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + c * 32 + fr) * WPITCH + ks * 32 + fh * 16);
 #pragma unroll
-            for (int a = 0; a < 2; ++a)
+            for (int a = 0; a < MT; ++a)
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            wg_store(lds + (cur ^ 1) * 2 * WTILE_BYTES, ra, tid);
-            wg_store(lds + (cur ^ 1) * 2 * WTILE_BYTES + WTILE_BYTES, rb, tid);
+            wg_store<NVA>(lds + (cur ^ 1) * BUF, ra, tid);
+            wg_store<4>(lds + (cur ^ 1) * BUF + ATILE, rb, tid);
         }
         __syncthreads();
     }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); rows = o, cols = i
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < MT; ++a)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             const int col = i0 + wc * 64 + c * 32 + fr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = o0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                const int row = o0 + wr * 32 * MT + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
                 if (row < p.O && col < p.I) atomicAdd(&p.gw[(long long)row * p.I + col], acc[a][c][r]);
             }
         }
@@ -152,12 +159,14 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     p.I = cin;
     p.B = batch;
     p.P = P;
+    const int MT = 2;   // 128 x 128 blocks (MT = 4: 256-row blocks at one workgroup per CU measured slower)
+    const int WTO = 64 * MT;
     p.nblk_o = mk::ceil_div(cout, WTO);
     p.nblk_i = mk::ceil_div(cin, WTI);
     // slab length: enough workgroups to fill the chip (>= ~1500), at least 512 pixels each
     {
         const long long nblk = (long long)p.nblk_o * p.nblk_i * batch;
-        long long want = (1536 + nblk - 1) / nblk;              // slabs per batch item
+        long long want = (MK_WGRAD_TARGET + nblk - 1) / nblk;   // slabs per batch item
         long long slab = (P + want - 1) / want;
         slab = (slab + 63) / 64 * 64;
         if (slab < 512) slab = 512;
@@ -167,7 +176,11 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     const long long nslab_tot = (long long)p.nslab * batch;
     const long long grid = ((nslab_tot + 7) / 8) * 8 * p.nblk_o * p.nblk_i;
     MK_REQUIRE(grid < 2147483647LL, "grid too large");
-    hipLaunchKernelGGL(conv1x1_wgrad_kernel, dim3((unsigned)grid), dim3(WT), 4 * WTILE_BYTES, (hipStream_t)stream, p);
+    const size_t lds = 2 * (size_t)(WTO * WPITCH + WTILE_BYTES);
+    if (MT == 4)
+        hipLaunchKernelGGL(conv1x1_wgrad_kernel<4>, dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
+    else
+        hipLaunchKernelGGL(conv1x1_wgrad_kernel<2>, dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
     MK_LAUNCH_CHECK();
     return 0;
 }
