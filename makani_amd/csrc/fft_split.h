@@ -24,6 +24,12 @@ constexpr int SLDS_F2 = SNSUB * SP + 96;
 
 __device__ __forceinline__ int sub_base(int sr, int S) { return sr * SP + 4 * (sr / S); }
 __device__ __forceinline__ int phi(int i) { return i + (i >> 4); }
+// an opaque copy of a value: stops the compiler from hoisting per-tile index arithmetic out of the
+// persistent tile loop (which costs ~100 VGPRs of precomputed offsets and an occupancy level)
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 
 // radix-16 then radix-15 on the sub-row owned by this lane group; tw15[r] = exp(-2 pi i k r / 240)
 __device__ __forceinline__ void split_passes(float2* lds, int tid, int S, const float2 (&tw15)[15]) {
@@ -51,6 +57,9 @@ __device__ __forceinline__ void split_passes(float2* lds, int tid, int S, const 
 template <typename T> struct InVec;
 template <> struct InVec<float> {
     static constexpr int E = 4;
+    static __device__ __forceinline__ void unpack(const uint4& v, float (&o)[4]) {
+        o[0] = __uint_as_float(v.x); o[1] = __uint_as_float(v.y); o[2] = __uint_as_float(v.z); o[3] = __uint_as_float(v.w);
+    }
     static __device__ __forceinline__ void load(const float* p, float (&o)[4]) {
         const float4 v = *reinterpret_cast<const float4*>(p);
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -58,6 +67,14 @@ template <> struct InVec<float> {
 };
 template <> struct InVec<__hip_bfloat16> {
     static constexpr int E = 8;
+    static __device__ __forceinline__ void unpack(const uint4& v, float (&o)[8]) {
+        const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
     static __device__ __forceinline__ void load(const __hip_bfloat16* p, float (&o)[8]) {
         const uint4 v = *reinterpret_cast<const uint4*>(p);
         const unsigned int w[4] = {v.x, v.y, v.z, v.w};
@@ -192,16 +209,17 @@ template <> struct OutVec<__hip_bfloat16> {
 };
 
 template <int S, typename TOut>
-__global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
+__global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
                                                                float scale0, float scale_m, float scale_h) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int ntile = (BC + G - 1) / G;
-    const int k = blockIdx.x / ntile;
-    const int bc0 = (blockIdx.x - k * ntile) * G;
+    const int total = ntile * K;
     const float2* tw2 = tw + HH;
+    int tile = blockIdx.x;          // persistent: this workgroup walks tiles tile, tile + gridDim.x, ...
+    if (tile >= total) return;
 
     float2 tw15[15];
 #pragma unroll
@@ -213,21 +231,28 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
     constexpr int NPAIR = SH / 2 + 1;
     constexpr int PIT = (G * NPAIR + STHREADS - 1) / STHREADS;
     float2 xa[PIT], xb[PIT];
+    auto gather = [&](int t, int tl) {      // the 8-byte mode gathers of tile t (in flight while the previous tile computes)
+        const int k = t / ntile, bc0 = (t - k * ntile) * G;
 #pragma unroll
-    for (int it = 0; it < PIT; ++it) {
-        const int idx = tid + it * STHREADS;
-        const int jp = idx / G, g = idx - jp * G;
-        const int bc = bc0 + g, j1 = SH - jp;
-        xa[it] = make_float2(0.f, 0.f);
-        xb[it] = make_float2(0.f, 0.f);
-        if (idx < G * NPAIR && bc < BC) {
-            if (jp < M) xa[it] = xf[((size_t)jp * K + k) * BC + bc];
-            if (j1 < M) xb[it] = xf[((size_t)j1 * K + k) * BC + bc];
+        for (int it = 0; it < PIT; ++it) {
+            const int idx = tl + it * STHREADS;
+            const int jp = idx / G, g = idx - jp * G;
+            const int bc = bc0 + g, j1 = SH - jp;
+            xa[it] = make_float2(0.f, 0.f);
+            xb[it] = make_float2(0.f, 0.f);
+            if (idx < G * NPAIR && bc < BC) {
+                if (jp < M) xa[it] = xf[((size_t)jp * K + k) * BC + bc];
+                if (j1 < M) xb[it] = xf[((size_t)j1 * K + k) * BC + bc];
+            }
         }
-    }
+    };
+    gather(tile, tid);
+  for (;;) {
+    const int tl = opaque(tid);
+    const int k = tile / ntile, bc0 = (tile - k * ntile) * G;
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
-        const int idx = tid + it * STHREADS;
+        const int idx = tl + it * STHREADS;
         if (idx >= G * NPAIR) continue;
         const int jp = idx / G, g = idx - jp * G;
         const int j1 = SH - jp;
@@ -260,7 +285,9 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
         }
     }
     __syncthreads();
-    split_passes(lds, tid, S, tw15);
+    const int next = tile + (int)gridDim.x;
+    if (next < total) gather(next, opaque(tid));
+    split_passes(lds, tl, S, tw15);
     __syncthreads();
 
     // copy-out: groups of EO*S reals = EO reals (EO/2 complex, contiguous in the padded image) of every
@@ -269,7 +296,7 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
     constexpr int GPR = N / (EO * S), NGRP = G * GPR, OIT = (NGRP + STHREADS - 1) / STHREADS;
 #pragma unroll
     for (int it = 0; it < OIT; ++it) {
-        const int v = tid + it * STHREADS;
+        const int v = tl + it * STHREADS;
         const int g = v / GPR, p = v - g * GPR;
         if (v < NGRP && bc0 + g < BC) {
             float r[S][EO];
@@ -296,13 +323,33 @@ __global__ __launch_bounds__(STHREADS) void irfft_split_kernel(const float2* __r
             }
         }
     }
+    if (next >= total) break;
+    tile = next;
+    __syncthreads();   // the image is rewritten by the next tile's merge step
+  }
+}
+
+// persistent launch: MK_FFT_WGS workgroups per CU (default 2) walk the tiles; 0 = one workgroup per tile
+static inline unsigned split_grid(long long tiles) {
+    static const int per_cu = [] {
+        const char* e = getenv("MK_FFT_WGS");
+        return e ? atoi(e) : 2;
+    }();
+    static const int cus = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 256;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
+        return v;
+    }();
+    const long long cap = (long long)per_cu * cus;
+    return (unsigned)((per_cu > 0 && tiles > cap) ? cap : tiles);
 }
 
 template <int S>
 int launch_rfft_split(const void* x, int x_dtype, float* xf, const float* tw, int bc, int nlat, int mmax, float s0,
                       float sm, float sh, hipStream_t st) {
     constexpr int G = SNSUB / S;
-    const dim3 grid((unsigned)(mk::ceil_div(bc, G) * nlat));
+    const dim3 grid((unsigned)(mk::ceil_div(bc, G) * nlat));   // one workgroup per tile (persistence costs it 70 VGPRs)
     const size_t lds = sizeof(float2) * SLDS_F2;
     if (x_dtype == 0)
         hipLaunchKernelGGL((rfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float*)x, (float2*)xf,
@@ -317,7 +364,7 @@ template <int S>
 int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, int bc, int nlat, int mmax, float s0,
                        float sm, float sh, hipStream_t st) {
     constexpr int G = SNSUB / S;
-    const dim3 grid((unsigned)(mk::ceil_div(bc, G) * nlat));
+    const dim3 grid(split_grid(mk::ceil_div(bc, G) * (long long)nlat));
     const size_t lds = sizeof(float2) * SLDS_F2;
     if (x_dtype == 0)
         hipLaunchKernelGGL((irfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (float*)x,

@@ -77,6 +77,8 @@ def main():
         if not only or "irfft" in only:
             ms, b = timeit(lambda: ops.irfft_raw(xf, tw, N, 1.0, 1.0, 1.0), args.iters)
             report("irfft", shape, ms, b, fft_bytes, "byte")
+            ms, b = timeit(lambda: ops.irfft_raw(xf, tw, N, 1.0, 1.0, 1.0, torch.bfloat16), args.iters)
+            report("irfft(bf16 out)", shape, ms, b, K * bc * (2 * N + 8 * M), "byte")
         tabw = ops.legendre_table(grid, K, L, M, True).to(dev)
         c = ops.legendre_fwd_raw(xf, tabw, L)
         leg_flop = 4.0 * T * K * bc
