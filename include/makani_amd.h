@@ -99,6 +99,22 @@ int mk_legendre_fwd(const float* xf, const float* tab, float* c,
 int mk_legendre_inv(const float* c, const float* tab, float* xf,
                     int bc, int nlat, int lmax, int mmax_loc, int m_off, int mmax_glob, void* stream);
 
+/* ---- the same contractions on the bf16 matrix cores, fp32-accurate ("bf16x3") ----------
+ * Every fp32 operand is split exactly into three bf16 pieces and each product is evaluated
+ * as the six leading piece products, accumulated in fp32 (error ~2^-22 relative, same
+ * parity budget as above).  The table is pre-split once into the kernels' tile images:
+ *   inverse = 0: for contractions over latitude  (mk_legendre_fwd_x3)
+ *   inverse = 1: for contractions over degree    (mk_legendre_inv_x3)
+ * mk_legendre_x3_bytes: size of the image; mk_legendre_x3_split: fp32 device table
+ * [mmax][lmax][kpad] (mk_legendre_table) -> image (device). */
+long long mk_legendre_x3_bytes(int nlat, int lmax, int mmax, int inverse);
+int mk_legendre_x3_split(const float* tab, void* out, int nlat, int lmax, int mmax, int inverse, void* stream);
+/* Same contracts as mk_legendre_fwd / mk_legendre_inv with `tab_x3` the matching image. */
+int mk_legendre_fwd_x3(const float* xf, const void* tab_x3, float* c,
+                       int bc, int nlat, int lmax, int mmax_loc, int m_off, int mmax_glob, void* stream);
+int mk_legendre_inv_x3(const float* c, const void* tab_x3, float* xf,
+                       int bc, int nlat, int lmax, int mmax_loc, int m_off, int mmax_glob, void* stream);
+
 /* ---- spectral filter contraction (K5) ---------------------------------- */
 /* y[l][m][b][o] = sum_i x[l][m][b][i] * w[l][i][o]  (complex), for global m <= l.
  * Replaces _contract_dhconv `einsum("bixy,iox->boxy")` (contractions.py:130-136,
@@ -112,6 +128,15 @@ int mk_dhconv_dgrad(const float* gy, const float* w, float* gx, int lloc, int ml
 /* gw[l][i][o] = sum_{m<=l, b} conj(x[l][m][b][i]) * gy[l][m][b][o] */
 int mk_dhconv_wgrad(const float* x, const float* gy, float* gw, int lloc, int mloc, int batch,
                     int cin, int cout, int l_off, int m_off, void* stream);
+
+/* bf16x3 variants of the three dhconv kernels (see the Legendre section): same contracts,
+ * cin and cout must be even (returns an error otherwise; the fp32 kernels take any size). */
+int mk_dhconv_fwd_x3(const float* x, const float* w, float* y, int lloc, int mloc, int batch,
+                     int cin, int cout, int l_off, int m_off, void* stream);
+int mk_dhconv_dgrad_x3(const float* gy, const float* w, float* gx, int lloc, int mloc, int batch,
+                       int cin, int cout, int l_off, int m_off, void* stream);
+int mk_dhconv_wgrad_x3(const float* x, const float* gy, float* gw, int lloc, int mloc, int batch,
+                       int cin, int cout, int l_off, int m_off, void* stream);
 
 /* ---- layout conversion -------------------------------------------------- */
 /* torch [BC][L][M] complex64  <->  private [L][M][BC] complex64.  unpack writes

@@ -32,9 +32,16 @@ SIGNATURES = {
     "mk_irfft": (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _vp]),
     "mk_legendre_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_legendre_inv": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_legendre_x3_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int, _c_int]),
+    "mk_legendre_x3_split": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_legendre_fwd_x3": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
+    "mk_legendre_inv_x3": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_dhconv_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "mk_dhconv_dgrad": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "mk_dhconv_wgrad": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_dhconv_fwd_x3": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_dhconv_dgrad_x3": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_dhconv_wgrad_x3": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "mk_spec_pack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "mk_spec_unpack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_bias_gelu_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),

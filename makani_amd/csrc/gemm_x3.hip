@@ -1,0 +1,709 @@
+// fp32-accurate GEMM engine on the bf16 matrix cores ("bf16x3") for the Legendre contraction (K2 / K3)
+// and the dhconv spectral filter (K5) on gfx950.
+//
+// CDNA4 has no TF32 and its fp32 MFMA runs at 1/16 of the bf16 rate.  Every fp32 operand is therefore
+// split EXACTLY into three bf16 pieces  x = h + m + l  (8 + 8 + 8 significand bits, by truncation) and a
+// product is evaluated as the six piece products of weight >= 2^-16
+//     a*b ~= ah*bh + ah*bm + am*bh + ah*bl + am*bm + al*bh          (dropped terms <= 3 * 2^-24 |a b|)
+// with v_mfma_f32_32x32x16_bf16 accumulating in fp32: fp32-level accuracy at 16/6 = 2.7x the fp32-MFMA
+// rate.  The 1e-5 parity budget of the spectral path is met with two orders of magnitude to spare
+// (tests/test_kernels_gpu.py compares against the float64 oracle).
+//
+// One 256-thread workgroup (4 waves, 2 x 2) owns a 128 x 128 tile of C and walks the contraction in steps
+// of 32.  LDS holds ONE stage: per operand 128 rows x [3 pieces][32 k] bf16 (192 B, pitch 208 B so the
+// ds_read_b128 fragment reads and the ds_write_b128 staging writes are bank-conflict free); the next
+// k-step is prefetched into registers while the MFMAs run and converted / written after a barrier
+// (53.5 KB -> 3 workgroups per CU cover each other's staging phases).  Measured alternatives: a register ring
+// 2-4 k-steps deep for the streamed operand (2 workgroups per CU) and a 512-thread 256 x 128 tile with two
+// LDS stages (1 per CU) were both slower -- the load path runs at its throughput for this HBM / L2 mix
+// (~43 GB/s per CU) and only occupancy overlaps it with the MFMA phase.
+//
+// Operands whose contraction index is the slow memory axis (k-major rows, n contiguous) are transposed
+// in the staging pass: a thread loads 8 consecutive k of two adjacent columns (float2 per row, 512 B per
+// wave and row), splits them and writes one 16-byte [8 k] vector per piece and column.  Constant operands
+// (the Legendre tables) are pre-split once into the exact LDS image, tile by tile, so staging them is a
+// straight 24 KB copy.
+#include "common.h"
+#include "../../include/makani_amd.h"
+
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP uint4 arrays end up in scratch
+
+constexpr int XT = 256;                       // threads
+constexpr int XM = 128, XN = 128, XK = 32;    // workgroup tile, k-step
+constexpr int XPITCH = 208;                   // LDS row pitch: 192 data + 16 pad (13 x 16 B: odd)
+constexpr int XROWB = 192;                    // bytes of one row per k-step: [3][32] bf16
+constexpr int XIMG = XM * XPITCH + 128;       // one operand image (+128: offset of the odd half, see pair_off)
+constexpr int X3_LDS = 2 * XIMG;              // 53,504 B
+constexpr int XCHUNK = XM * XROWB;            // 24,576 B: one pre-split [128 rows][3][32] block in HBM
+
+// LDS row offsets.  plain: row r at r * pitch.  pair: rows 2t, 2t+1 are written by one thread (lane t), so
+// they live 64 rows (+128 B) apart -- 8 consecutive lanes then hit 8 consecutive rows (conflict-free
+// stores) and a fragment read of 16 consecutive rows still covers all 64 banks.
+__device__ __forceinline__ int plain_off(int r) { return r * XPITCH; }
+__device__ __forceinline__ int pair_off(int r) { return ((r >> 1) + ((r & 1) << 6)) * XPITCH + ((r & 1) << 7); }
+
+// exact three-way split; the bf16 pieces are the UPPER halves of the returned words
+struct Split3 {
+    uint32_t h, m, l;
+};
+__device__ __forceinline__ Split3 split3(float x) {
+    Split3 s;
+    s.h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r1 = x - __uint_as_float(s.h);
+    s.m = __float_as_uint(r1) & 0xFFFF0000u;
+    s.l = __float_as_uint(r1 - __uint_as_float(s.m));   // <= 8 significant bits left: truncation is exact
+    return s;
+}
+// (upper half of e1) : (upper half of e0)
+__device__ __forceinline__ uint32_t pack_hi(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+
+// split 8 consecutive-k values and store them as one 16-byte vector per piece at `dst` (+64 B per piece)
+__device__ __forceinline__ void split_store8(const float (&v)[8], char* dst) {
+    Split3 s[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s[i] = split3(v[i]);
+    uint4 h, m, l;
+    h.x = pack_hi(s[0].h, s[1].h); h.y = pack_hi(s[2].h, s[3].h); h.z = pack_hi(s[4].h, s[5].h); h.w = pack_hi(s[6].h, s[7].h);
+    m.x = pack_hi(s[0].m, s[1].m); m.y = pack_hi(s[2].m, s[3].m); m.z = pack_hi(s[4].m, s[5].m); m.w = pack_hi(s[6].m, s[7].m);
+    l.x = pack_hi(s[0].l, s[1].l); l.y = pack_hi(s[2].l, s[3].l); l.z = pack_hi(s[4].l, s[5].l); l.w = pack_hi(s[6].l, s[7].l);
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + 64) = m;
+    *reinterpret_cast<uint4*>(dst + 128) = l;
+}
+
+// ---------------------------------------------------------------------------
+// Stagers: Regs, gload(kt, regs, tid), sstore(regs, image, tid), row_off(r)
+// ---------------------------------------------------------------------------
+
+// Pre-split constant operand: k-step kt of this tile is the contiguous XCHUNK block base + kt * XCHUNK.
+// All 128 rows are copied unconditionally: skipping the dead rows of ragged tiles behind (wave-uniform)
+// branches measured 10-15 % slower than the straight copy.
+struct PresplitStager {
+    const char* base;
+    typedef u32x4 Regs[6];
+    static __device__ __forceinline__ int row_off(int r) { return plain_off(r); }
+    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+        const char* p = base + (long long)kt * XCHUNK + tid * 16;
+#pragma unroll
+        for (int q = 0; q < 6; ++q) r[q] = *reinterpret_cast<const u32x4*>(p + q * XT * 16);
+    }
+    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) {
+            const int g = tid + q * XT;
+            const int row = g / 12, c = g - row * 12;
+            *reinterpret_cast<u32x4*>(img + row * XPITCH + c * 16) = r[q];
+        }
+    }
+};
+
+// Dead rows / columns of an image may hold anything: they only feed outputs that are never stored.  Indices
+// past the contraction range must read as zero.
+
+// k-major fp32 operand: element (k, c) = base[k * ldk + c]; tile rows are the 128 columns c (pairs 2t, 2t+1
+// per lane t), valid for k_lo <= k < k_hi and c < cvalid (cvalid even).
+struct TransStager {
+    const float* base;
+    long long ldk;
+    int k_lo, k_hi, cvalid;
+    typedef float2 Regs[8];
+    static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
+    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+        const int w = tid >> 6, c = (tid & 63) * 2;
+        const int k0 = kt * XK + w * 8;
+        const float* p = base + (c < cvalid ? c : 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = k0 + i;
+            const bool ok = k >= k_lo && k < k_hi;
+            int kc = k < k_lo ? k_lo : k;
+            kc = kc < k_hi ? kc : k_hi - 1;   // k_hi >= 1; also covers an empty range (k_lo >= k_hi)
+            const float2 v = *reinterpret_cast<const float2*>(p + (long long)kc * ldk);
+            r[i] = ok ? v : make_float2(0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
+        const int w = tid >> 6, t = tid & 63;
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            a[i] = r[i].x;
+            b[i] = r[i].y;
+        }
+        split_store8(a, img + t * XPITCH + w * 16);
+        split_store8(b, img + (t + 64) * XPITCH + 128 + w * 16);
+    }
+};
+
+// Row-major fp32 A operand, k contiguous: element (r, k) = base[r * ld + k], rows < rows, k < kvalid
+// (kvalid a multiple of 4, rows 16-byte aligned).  Two (row, 8 k) tasks per thread.
+struct RowStager {
+    const float* base;
+    long long ld;
+    int rows, kvalid;
+    typedef float4 Regs[4];
+    static __device__ __forceinline__ int row_off(int r) { return plain_off(r); }
+    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = tid + q * XT, row = t >> 2, k = kt * XK + (t & 3) * 8;
+            const float* p = base + (long long)row * ld + k;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                r[2 * q + h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < rows && k + 4 * h < kvalid) r[2 * q + h] = *reinterpret_cast<const float4*>(p + 4 * h);
+            }
+        }
+    }
+    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int t = tid + q * XT, row = t >> 2;
+            const float v[8] = {r[2 * q].x, r[2 * q].y, r[2 * q].z, r[2 * q].w, r[2 * q + 1].x, r[2 * q + 1].y, r[2 * q + 1].z, r[2 * q + 1].w};
+            if (row < rows) split_store8(v, img + row * XPITCH + (t & 3) * 16);
+        }
+    }
+};
+
+// Complex k-major B operand: element (kk, o) = (base[(kk * ldk + o) * 2], base[... + 1]), kk < kk_hi,
+// o < ovalid.  Complex column o becomes the image rows n = 2o (real part of the product) and 2o + 1
+// (imaginary part); complex row kk the contraction indices k = 2kk, 2kk + 1:
+//   CONJ_B = false (dhconv forward, B = w):       row 2o: [ re, -im ]   row 2o+1: [ im,  re ]
+//   CONJ_B = true  (dhconv wgrad,  B = gy, the conjugate sits on the A side): row 2o: [ re, im ]  row 2o+1: [ im, -re ]
+template <bool CONJ_B>
+struct CplxStager {
+    const float* base;
+    long long ldk;
+    int kk_hi, ovalid;
+    typedef float2 Regs[4];
+    static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
+    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), o = tid & 63;
+        const int kk0 = kt * (XK / 2) + w * 4;
+        const bool ook = o < ovalid;
+        const float* p = base + ((long long)kk0 * ldk + (ook ? o : 0)) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float2 v = make_float2(0.f, 0.f);
+            if (kk0 + i < kk_hi) v = *reinterpret_cast<const float2*>(p + (long long)i * ldk * 2);
+            r[i] = ook ? v : make_float2(0.f, 0.f);
+        }
+    }
+    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
+        const int w = tid >> 6, t = tid & 63;
+        float a[8], b[8];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            a[2 * i] = r[i].x;
+            a[2 * i + 1] = CONJ_B ? r[i].y : -r[i].y;
+            b[2 * i] = r[i].y;
+            b[2 * i + 1] = CONJ_B ? -r[i].x : r[i].x;
+        }
+        split_store8(a, img + t * XPITCH + w * 16);
+        split_store8(b, img + (t + 64) * XPITCH + 128 + w * 16);
+    }
+};
+
+// dhconv dgrad B operand: gx[(i,c)] = sum_(o,d) gy[(o,d)] * B[(o,d)][(i,c)] with B = conj(w)^T.  Complex
+// w[i][o] at base[(i * O + o) * 2]; image rows n = 2i (-> real part), 2i + 1 (-> imaginary part), contraction
+// k = 2o + d:   row 2i: [ re, im ]   row 2i+1: [ -im, re ].   A thread loads 4 consecutive o of one i.
+struct DgradStager {
+    const float* base;
+    int O, ivalid;
+    typedef float4 Regs[2];
+    static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
+    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+        const int i = tid >> 2, o = kt * (XK / 2) + (tid & 3) * 4;
+        const float* p = base + ((long long)i * O + o) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            r[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (i < ivalid && o + 2 * h < O) r[h] = *reinterpret_cast<const float4*>(p + 4 * h);
+        }
+    }
+    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
+        const int i = tid >> 2, c = tid & 3;
+        const float a[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
+        const float b[8] = {-r[0].y, r[0].x, -r[0].w, r[0].z, -r[1].y, r[1].x, -r[1].w, r[1].z};
+        split_store8(a, img + i * XPITCH + c * 16);
+        split_store8(b, img + (i + 64) * XPITCH + 128 + c * 16);
+    }
+};
+
+// dhconv wgrad A operand: gw[i][(o,d)] = sum_(r,c) A[i][(r,c)] * B[(r,c)][(o,d)] with A[i][(r,0)] = re x[r][i],
+// A[i][(r,1)] = im x[r][i] (the conjugate is in CplxStager<true>'s signs).  Complex x[r][i] at
+// base[(r * I + i) * 2]; image row i holds, per 4 rows r, [re, im] x 4.  Two columns i per thread.
+struct WgradAStager {
+    const float* base;
+    long long I;
+    int r_hi, ivalid;
+    typedef float2 Regs[8];
+    static __device__ __forceinline__ int row_off(int r) { return plain_off(r); }
+    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+        const int w = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
+        const int r0 = kt * (XK / 2) + w * 4;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int i = t + 64 * e;
+            const bool iok = i < ivalid;
+            const float* p = base + ((long long)r0 * I + (iok ? i : 0)) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float2 v = make_float2(0.f, 0.f);
+                if (r0 + j < r_hi) v = *reinterpret_cast<const float2*>(p + (long long)j * I * 2);
+                r[4 * e + j] = iok ? v : make_float2(0.f, 0.f);
+            }
+        }
+    }
+    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
+        const int w = tid >> 6, t = tid & 63;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const float v[8] = {r[4 * e].x, r[4 * e].y, r[4 * e + 1].x, r[4 * e + 1].y,
+                                r[4 * e + 2].x, r[4 * e + 2].y, r[4 * e + 3].x, r[4 * e + 3].y};
+            split_store8(v, img + (t + 64 * e) * XPITCH + w * 16);
+        }
+    }
+};
+
+// One k-step (2 x k16) of a wave's 64 x 64 sub-tile from the LDS images: six piece products, smallest first,
+// alternating between the two accumulators of a 32-row band.  A band whose rows are all past the valid
+// extent gets no MFMA work (wave-uniform test).
+__device__ __forceinline__ void x3_mfma_step(const char* As, const char* Bs, const int (&a_off)[2], const int (&b_off)[2],
+                                             const bool (&live)[2], f32x16 (&acc)[2][2]) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        bf16x8 bf[2][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8*>(Bs + b_off[b] + p * 64 + s * 32);
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+            if (live[a]) {
+                bf16x8 af[3];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + a_off[a] + p * 64 + s * 32);
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int b = 0; b < 2; ++b)
+                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]], bf[b][PB[t]], acc[a][b], 0, 0, 0);
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The tile: C[128 x 128] (+)= A * B over k-steps [kt0, kt1)
+// ---------------------------------------------------------------------------
+// Accumulator (a, b) of wave (wr, wc) holds rows wr*64 + a*32 + [0,32) and the columns of parity b of
+// wc*64 + [0,64) (column 2j + b in MFMA column j), so a lane owns adjacent column pairs and the epilogue
+// writes 8-byte values, 256 B per row and wave.
+// The B operand streams from HBM: it is prefetched DB k-steps ahead through a ring of register sets (the
+// loop is unrolled DB times so ring slots are compile-time); the A operand (L2-resident panels) one ahead.
+template <int DB, class AS, class BS>
+__device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int kt1, int rvalid, int cvalid, float* cbase,
+                                        long long ldc, char* lds, int exp = 0) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: liveness tests stay scalar
+    const int wr = wave >> 1, wc = wave & 1;
+    const int fi = lane & 31, kg = lane >> 5;
+    char* As = lds;
+    char* Bs = lds + XIMG;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    bool live[2];
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        a_off[a] = AS::row_off(wr * 64 + a * 32 + fi) + kg * 16;
+        b_off[a] = BS::row_off(wc * 64 + 2 * fi + a) + kg * 16;
+        live[a] = (wr * 64 + a * 32 < rvalid) && (wc * 64 < cvalid);
+    }
+
+    typename AS::Regs ra;
+    typename BS::Regs rb[DB];
+    if (kt0 < kt1) {
+        as.gload(kt0, ra, tid);
+        bs.gload(kt0, rb[0], tid);
+        as.sstore(ra, As, tid);
+        bs.sstore(rb[0], Bs, tid);
+        __syncthreads();
+        if (kt0 + 1 < kt1) as.gload(kt0 + 1, ra, tid);
+#pragma unroll
+        for (int j = 0; j < DB; ++j)
+            if (kt0 + 1 + j < kt1) bs.gload(kt0 + 1 + j, rb[j], tid);
+    }
+    for (int ktb = kt0; ktb < kt1; ktb += DB) {
+#pragma unroll
+        for (int j = 0; j < DB; ++j) {   // ring slot j holds k-step kt + 1
+            const int kt = ktb + j;
+            if (kt >= kt1) break;
+            if (!(exp & 4)) x3_mfma_step(As, Bs, a_off, b_off, live, acc);
+            if (kt + 1 < kt1) {
+                __syncthreads();
+                if (!(exp & 2)) {
+                    as.sstore(ra, As, tid);
+                    bs.sstore(rb[j], Bs, tid);
+                }
+                __syncthreads();
+                if (!(exp & 1)) {
+                    if (kt + 2 < kt1 && !(exp & 8)) as.gload(kt + 2, ra, tid);
+                    if (kt + 1 + DB < kt1 && !(exp & 16)) bs.gload(kt + 1 + DB, rb[j], tid);
+                }
+            }
+        }
+    }
+    // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int col = wc * 64 + 2 * fi;
+    if (col < cvalid) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+                if (row < rvalid)
+                    *reinterpret_cast<float2*>(cbase + (long long)row * ldc + col) = make_float2(acc[a][0][r], acc[a][1][r]);
+            }
+    }
+}
+
+// block -> (batch, tile_m, tile_n): all tiles of one batch index on one XCD (blockIdx % 8), back to back
+struct TileId {
+    int batch, tm, tn;
+    bool valid;
+};
+__device__ __forceinline__ TileId decode_block(int nbatch, int tiles_m, int tiles_n) {
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = bid >> 3;
+    const int T = tiles_m * tiles_n;
+    TileId t;
+    t.batch = (q / T) * 8 + xcd;
+    const int r = q % T;
+    t.tm = r / tiles_n;
+    t.tn = r - t.tm * tiles_n;
+    t.valid = t.batch < nbatch;
+    return t;
+}
+static inline long long grid_blocks(int nbatch, int tiles_m, int tiles_n) {
+    return (long long)mk::ceil_div(nbatch, 8) * 8 * tiles_m * tiles_n;
+}
+
+static int x3_exp() {
+    static const int v = [] { const char* e = getenv("MK_X3_EXP"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+// ---------------------------------------------------------------------------
+// Legendre analysis / synthesis
+// ---------------------------------------------------------------------------
+struct LegX3Params {
+    const float* src;
+    const char* tab;   // pre-split table (mk_legendre_x3_split)
+    float* dst;
+    int K, L, Mloc, m_off, N2;
+    int RT;   // analysis layout: 128-row tiles per m (rows l = m + 128 rt + r);  synthesis layout: k tiles
+    int KC;   // analysis layout: 32-k chunks;                                   synthesis layout: 32-l chunks
+    int tiles_n;
+    int exp;  // ablation switches (MK_X3_EXP): 1 no prefetch loads, 2 no staging stores, 4 no MFMAs -- wrong results
+};
+
+// c[l][m][:] = sum_k W[m][l][k] xf[m][k][:]   (rows l >= m only)
+__global__ __launch_bounds__(XT, 3) void legendre_fwd_x3_kernel(LegX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_x3[];
+    const TileId t = decode_block(p.Mloc, p.RT, p.tiles_n);
+    if (!t.valid) return;
+    const int m = t.batch, mg = p.m_off + m;
+    const int l0 = mg + t.tm * XM;
+    if (l0 >= p.L) return;
+    const int n0 = t.tn * XN;
+    PresplitStager as;
+    as.base = p.tab + ((long long)mg * p.RT + t.tm) * p.KC * XCHUNK;
+    TransStager bs;
+    bs.base = p.src + (long long)m * p.K * p.N2 + n0;
+    bs.ldk = p.N2;
+    bs.k_lo = 0;
+    bs.k_hi = p.K;
+    bs.cvalid = p.N2 - n0;
+    x3_tile<1>(as, bs, 0, p.KC, p.L - l0, p.N2 - n0, p.dst + ((long long)l0 * p.Mloc + m) * p.N2 + n0,
+            (long long)p.Mloc * p.N2, lds_x3, p.exp);
+}
+
+// xf[m][k][:] = sum_{l >= m} P[m][l][k] c[l][m][:]
+__global__ __launch_bounds__(XT, 3) void legendre_inv_x3_kernel(LegX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_x3[];
+    const TileId t = decode_block(p.Mloc, p.RT, p.tiles_n);
+    if (!t.valid) return;
+    const int m = t.batch, mg = p.m_off + m;
+    const int k0 = t.tm * XM;
+    if (k0 >= p.K) return;
+    const int n0 = t.tn * XN;
+    PresplitStager as;
+    as.base = p.tab + ((long long)mg * p.RT + t.tm) * p.KC * XCHUNK;
+    TransStager bs;
+    bs.base = p.src + (long long)m * p.N2 + n0;
+    bs.ldk = (long long)p.Mloc * p.N2;
+    bs.k_lo = mg;
+    bs.k_hi = p.L;
+    bs.cvalid = p.N2 - n0;
+    const int kt0 = mg >> 5;
+    x3_tile<1>(as, bs, kt0 < p.KC ? kt0 : p.KC, p.KC, p.K - k0, p.N2 - n0, p.dst + ((long long)m * p.K + k0) * p.N2 + n0,
+            (long long)p.N2, lds_x3, p.exp);
+}
+
+// ---------------------------------------------------------------------------
+// dhconv forward / dgrad / wgrad (same contracts as the fp32 kernels of gemm.hip; cin, cout even)
+// ---------------------------------------------------------------------------
+struct DhX3Params {
+    const float* a;   // x (fwd, wgrad) or gy (dgrad)
+    const float* b;   // w (fwd, dgrad) or gy (wgrad)
+    float* dst;
+    int Lloc, Mloc, B, I, O, l_off, m_off, tiles_m, tiles_n, exp;
+};
+
+__device__ __forceinline__ int dh_rows(const DhX3Params& p, int l) {
+    int nm = p.l_off + l - p.m_off + 1;  // local modes with global m <= global l
+    nm = nm < 0 ? 0 : (nm > p.Mloc ? p.Mloc : nm);
+    return nm * p.B;
+}
+
+// y[l][r][:] = x[l][r][:] * w[l]   (rows r = (m, b) with m <= l)
+__global__ __launch_bounds__(XT, 3) void dhconv_fwd_x3_kernel(DhX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_x3[];
+    const TileId t = decode_block(p.Lloc, p.tiles_m, p.tiles_n);
+    if (!t.valid) return;
+    const int l = p.Lloc - 1 - t.batch;  // heaviest degrees first
+    const int R = dh_rows(p, l);
+    const int r0 = t.tm * XM;
+    if (r0 >= R) return;
+    const int n0 = t.tn * XN;
+    const long long rowbase = (long long)l * p.Mloc * p.B + r0;
+    RowStager as;
+    as.base = p.a + rowbase * 2 * p.I;
+    as.ld = 2 * p.I;
+    as.rows = R - r0;
+    as.kvalid = 2 * p.I;
+    CplxStager<false> bs;
+    bs.base = p.b + ((long long)l * p.I * p.O + n0 / 2) * 2;
+    bs.ldk = p.O;
+    bs.kk_hi = p.I;
+    bs.ovalid = p.O - n0 / 2;
+    x3_tile<1>(as, bs, 0, (2 * p.I + XK - 1) / XK, R - r0, 2 * p.O - n0, p.dst + rowbase * 2 * p.O + n0, 2LL * p.O, lds_x3,
+               p.exp);
+}
+
+// gx[l][r][:] = gy[l][r][:] * conj(w[l])^T
+__global__ __launch_bounds__(XT, 3) void dhconv_dgrad_x3_kernel(DhX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_x3[];
+    const TileId t = decode_block(p.Lloc, p.tiles_m, p.tiles_n);
+    if (!t.valid) return;
+    const int l = p.Lloc - 1 - t.batch;
+    const int R = dh_rows(p, l);
+    const int r0 = t.tm * XM;
+    if (r0 >= R) return;
+    const int n0 = t.tn * XN;
+    const long long rowbase = (long long)l * p.Mloc * p.B + r0;
+    RowStager as;
+    as.base = p.a + rowbase * 2 * p.O;
+    as.ld = 2 * p.O;
+    as.rows = R - r0;
+    as.kvalid = 2 * p.O;
+    DgradStager bs;
+    bs.base = p.b + ((long long)l * p.I + n0 / 2) * p.O * 2;
+    bs.O = p.O;
+    bs.ivalid = p.I - n0 / 2;
+    x3_tile<1>(as, bs, 0, (2 * p.O + XK - 1) / XK, R - r0, 2 * p.I - n0, p.dst + rowbase * 2 * p.I + n0, 2LL * p.I, lds_x3,
+               p.exp);
+}
+
+// gw[l][i][:] = sum_r conj(x[l][r][i]) gy[l][r][:]
+__global__ __launch_bounds__(XT, 3) void dhconv_wgrad_x3_kernel(DhX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_x3[];
+    const TileId t = decode_block(p.Lloc, p.tiles_m, p.tiles_n);
+    if (!t.valid) return;
+    const int l = p.Lloc - 1 - t.batch;
+    const int R = dh_rows(p, l);   // contraction length (may be 0: the gradient of that degree is zero)
+    const int i0 = t.tm * XM;
+    if (i0 >= p.I) return;
+    const int n0 = t.tn * XN;
+    const long long rowbase = (long long)l * p.Mloc * p.B;
+    WgradAStager as;
+    as.base = p.a + (rowbase * p.I + i0) * 2;
+    as.I = p.I;
+    as.r_hi = R;
+    as.ivalid = p.I - i0;
+    CplxStager<true> bs;
+    bs.base = p.b + (rowbase * p.O + n0 / 2) * 2;
+    bs.ldk = p.O;
+    bs.kk_hi = R;
+    bs.ovalid = p.O - n0 / 2;
+    x3_tile<1>(as, bs, 0, (2 * R + XK - 1) / XK, p.I - i0, 2 * p.O - n0, p.dst + ((long long)l * p.I + i0) * 2 * p.O + n0,
+               2LL * p.O, lds_x3, p.exp);
+}
+
+// table [M][L][KP] fp32 -> pre-split image.  One thread per (block, row, kk).
+__global__ void legendre_x3_split_kernel(const float* __restrict__ tab, uint16_t* __restrict__ out, int K, int KP, int L,
+                                         int M, int RT, int KC, int inverse, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int kk = (int)(idx & 31);
+    const int r = (int)((idx >> 5) & 127);
+    long long blk = idx >> 12;
+    const int kc = (int)(blk % KC);
+    blk /= KC;
+    const int rt = (int)(blk % RT);
+    const int m = (int)(blk / RT);
+    int l, k;
+    if (!inverse) {
+        l = m + rt * XM + r;
+        k = kc * XK + kk;
+    } else {
+        k = rt * XM + r;
+        l = kc * XK + kk;
+    }
+    float v = 0.f;
+    if (l < L && k < K) v = tab[((long long)m * L + l) * KP + k];
+    const Split3 s = split3(v);
+    uint16_t* o = out + (idx >> 5) * 96 + kk;
+    o[0] = (uint16_t)(s.h >> 16);
+    o[32] = (uint16_t)(s.m >> 16);
+    o[64] = (uint16_t)(s.l >> 16);
+}
+
+static void x3_layout(int nlat, int lmax, int inverse, int* RT, int* KC) {
+    if (!inverse) {
+        *RT = mk::ceil_div(lmax, XM);
+        *KC = mk::ceil_div(nlat, XK);
+    } else {
+        *RT = mk::ceil_div(nlat, XM);
+        *KC = mk::ceil_div(lmax, XK);
+    }
+}
+
+}  // namespace
+
+extern "C" long long mk_legendre_x3_bytes(int nlat, int lmax, int mmax, int inverse) {
+    if (nlat <= 0 || lmax <= 0 || mmax <= 0) return 0;
+    int RT, KC;
+    x3_layout(nlat, lmax, inverse, &RT, &KC);
+    return (long long)mmax * RT * KC * XCHUNK;
+}
+
+extern "C" int mk_legendre_x3_split(const float* tab, void* out, int nlat, int lmax, int mmax, int inverse, void* stream) {
+    MK_REQUIRE(tab && out, "null pointer");
+    MK_REQUIRE(nlat > 0 && lmax > 0 && mmax > 0, "bad sizes");
+    int RT, KC;
+    x3_layout(nlat, lmax, inverse, &RT, &KC);
+    const long long total = (long long)mmax * RT * KC * XM * XK;
+    const long long nblk = (total + 255) / 256;
+    MK_REQUIRE(nblk < 2147483647LL, "grid too large");
+    hipLaunchKernelGGL(legendre_x3_split_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tab,
+                       (uint16_t*)out, nlat, mk_legendre_kpad(nlat), lmax, mmax, RT, KC, inverse, total);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+static int legendre_x3_launch(bool fwd, const float* src, const void* tab, float* dst, int bc, int nlat, int lmax,
+                              int mmax_loc, int m_off, hipStream_t st) {
+    LegX3Params p;
+    p.src = src;
+    p.tab = (const char*)tab;
+    p.dst = dst;
+    p.K = nlat;
+    p.L = lmax;
+    p.Mloc = mmax_loc;
+    p.m_off = m_off;
+    p.N2 = 2 * bc;
+    x3_layout(nlat, lmax, fwd ? 0 : 1, &p.RT, &p.KC);
+    p.tiles_n = mk::ceil_div(p.N2, XN);
+    p.exp = x3_exp();
+    const long long nblk = grid_blocks(mmax_loc, p.RT, p.tiles_n);
+    if (nblk >= 2147483647LL) return -1;
+    if (fwd)
+        hipLaunchKernelGGL(legendre_fwd_x3_kernel, dim3((unsigned)nblk), dim3(XT), X3_LDS, st, p);
+    else
+        hipLaunchKernelGGL(legendre_inv_x3_kernel, dim3((unsigned)nblk), dim3(XT), X3_LDS, st, p);
+    return 0;
+}
+
+extern "C" int mk_legendre_fwd_x3(const float* xf, const void* tab_x3, float* c, int bc, int nlat, int lmax, int mmax_loc,
+                                  int m_off, int mmax_glob, void* stream) {
+    MK_REQUIRE(xf && tab_x3 && c, "null pointer");
+    MK_REQUIRE(bc > 0 && nlat > 0 && lmax > 0 && mmax_loc > 0, "bad sizes");
+    MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
+    MK_REQUIRE(legendre_x3_launch(true, xf, tab_x3, c, bc, nlat, lmax, mmax_loc, m_off, (hipStream_t)stream) == 0,
+               "grid too large");
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_legendre_inv_x3(const float* c, const void* tab_x3, float* xf, int bc, int nlat, int lmax, int mmax_loc,
+                                  int m_off, int mmax_glob, void* stream) {
+    MK_REQUIRE(xf && tab_x3 && c, "null pointer");
+    MK_REQUIRE(bc > 0 && nlat > 0 && lmax > 0 && mmax_loc > 0, "bad sizes");
+    MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
+    MK_REQUIRE(legendre_x3_launch(false, c, tab_x3, xf, bc, nlat, lmax, mmax_loc, m_off, (hipStream_t)stream) == 0,
+               "grid too large");
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+static int dh_x3_check(const void* a, const void* b, const void* c, int lloc, int mloc, int batch, int cin, int cout,
+                       int l_off, int m_off) {
+    MK_REQUIRE(a && b && c, "null pointer");
+    MK_REQUIRE(lloc > 0 && mloc > 0 && batch > 0 && cin > 0 && cout > 0, "bad sizes");
+    MK_REQUIRE(l_off >= 0 && m_off >= 0, "negative shard offset");
+    MK_REQUIRE(cin % 2 == 0 && cout % 2 == 0, "the bf16x3 dhconv kernels need even channel counts (use the fp32 kernels)");
+    return 0;
+}
+
+extern "C" int mk_dhconv_fwd_x3(const float* x, const float* w, float* y, int lloc, int mloc, int batch, int cin,
+                                int cout, int l_off, int m_off, void* stream) {
+    if (int e = dh_x3_check(x, w, y, lloc, mloc, batch, cin, cout, l_off, m_off)) return e;
+    DhX3Params p{x, w, y, lloc, mloc, batch, cin, cout, l_off, m_off, mk::ceil_div(mloc * batch, XM),
+                 mk::ceil_div(2 * cout, XN), x3_exp()};
+    const long long nblk = grid_blocks(lloc, p.tiles_m, p.tiles_n);
+    MK_REQUIRE(nblk < 2147483647LL, "grid too large");
+    hipLaunchKernelGGL(dhconv_fwd_x3_kernel, dim3((unsigned)nblk), dim3(XT), X3_LDS, (hipStream_t)stream, p);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_dhconv_dgrad_x3(const float* gy, const float* w, float* gx, int lloc, int mloc, int batch, int cin,
+                                  int cout, int l_off, int m_off, void* stream) {
+    if (int e = dh_x3_check(gy, w, gx, lloc, mloc, batch, cin, cout, l_off, m_off)) return e;
+    DhX3Params p{gy, w, gx, lloc, mloc, batch, cin, cout, l_off, m_off, mk::ceil_div(mloc * batch, XM),
+                 mk::ceil_div(2 * cin, XN), x3_exp()};
+    const long long nblk = grid_blocks(lloc, p.tiles_m, p.tiles_n);
+    MK_REQUIRE(nblk < 2147483647LL, "grid too large");
+    hipLaunchKernelGGL(dhconv_dgrad_x3_kernel, dim3((unsigned)nblk), dim3(XT), X3_LDS, (hipStream_t)stream, p);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_dhconv_wgrad_x3(const float* x, const float* gy, float* gw, int lloc, int mloc, int batch, int cin,
+                                  int cout, int l_off, int m_off, void* stream) {
+    if (int e = dh_x3_check(x, gy, gw, lloc, mloc, batch, cin, cout, l_off, m_off)) return e;
+    DhX3Params p{x, gy, gw, lloc, mloc, batch, cin, cout, l_off, m_off, mk::ceil_div(cin, XM),
+                 mk::ceil_div(2 * cout, XN), x3_exp()};
+    const long long nblk = grid_blocks(lloc, p.tiles_m, p.tiles_n);
+    MK_REQUIRE(nblk < 2147483647LL, "grid too large");
+    hipLaunchKernelGGL(dhconv_wgrad_x3_kernel, dim3((unsigned)nblk), dim3(XT), X3_LDS, (hipStream_t)stream, p);
+    MK_LAUNCH_CHECK();
+    return 0;
+}

@@ -9,6 +9,7 @@ Private layouts (see the header): ``xf`` = complex64 ``[M, K, BC]``, spectrum =
 complex64 ``[L, M, BC]`` (channels last), dhconv weight = complex64 ``[L, I, O]``.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -103,7 +104,38 @@ def irfft_raw(xf, twiddles, nlon, s0, sm, sh, out_dtype=torch.float32):
     return x if x.dtype == out_dtype else x.to(out_dtype)
 
 
-def legendre_fwd_raw(xf, table, lmax, m_off=0):
+# Arithmetic of the spectral GEMMs (Legendre, dhconv): "bf16x3" = exact three-way bf16 split of every fp32
+# operand, six bf16 MFMA products, fp32 accumulation (fp32-accurate, csrc/gemm_x3.hip); "f32" = fp32 MFMA
+# (csrc/gemm.hip).  Both meet the 1e-5 parity budget; bf16x3 is the faster one on gfx950.
+SPECTRAL_GEMM = os.environ.get("MK_SPECTRAL_GEMM", "bf16x3")
+
+
+def _gemm_mode(mode):
+    mode = mode or SPECTRAL_GEMM
+    if mode not in ("bf16x3", "f32"):
+        raise ValueError(f"unknown spectral GEMM mode {mode!r} (bf16x3 | f32)")
+    return mode
+
+
+def legendre_x3_image(table, nlat, inverse):
+    """Pre-split tile image of a device fp32 Legendre table (built once, cached on the tensor object)."""
+    _need_cuda(table)
+    cache = table.__dict__.setdefault("_mk_x3", {})
+    key = (int(nlat), int(bool(inverse)))
+    img = cache.get(key)
+    if img is None:
+        lib = _lib.load()
+        mg, lmax, kp = table.shape
+        assert kp == legendre_kpad(nlat) and table.is_contiguous() and table.dtype == torch.float32
+        nbytes = lib.mk_legendre_x3_bytes(nlat, lmax, mg, key[1])
+        img = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
+        _lib.check(lib.mk_legendre_x3_split(table.data_ptr(), img.data_ptr(), nlat, lmax, mg, key[1], _stream()),
+                   "mk_legendre_x3_split")
+        cache[key] = img
+    return img
+
+
+def legendre_fwd_raw(xf, table, lmax, m_off=0, mode=None):
     """xf [Mloc, K, BC] -> spectrum [lmax, Mloc, BC]; rows l < m are left unwritten."""
     _need_cuda(xf, table)
     assert xf.is_contiguous() and xf.dtype == torch.complex64 and table.dtype == torch.float32
@@ -111,12 +143,17 @@ def legendre_fwd_raw(xf, table, lmax, m_off=0):
     mg, lt, kp = table.shape
     assert lt == lmax and kp == legendre_kpad(k), "Legendre table does not match the operand"
     c = torch.empty(lmax, mloc, bc, dtype=torch.complex64, device=xf.device)
-    _lib.check(_lib.load().mk_legendre_fwd(xf.data_ptr(), table.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
-                                           m_off, mg, _stream()), "mk_legendre_fwd")
+    if _gemm_mode(mode) == "bf16x3":
+        img = legendre_x3_image(table, k, 0)
+        _lib.check(_lib.load().mk_legendre_fwd_x3(xf.data_ptr(), img.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
+                                                  m_off, mg, _stream()), "mk_legendre_fwd_x3")
+    else:
+        _lib.check(_lib.load().mk_legendre_fwd(xf.data_ptr(), table.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
+                                               m_off, mg, _stream()), "mk_legendre_fwd")
     return c
 
 
-def legendre_inv_raw(c, table, nlat, m_off=0):
+def legendre_inv_raw(c, table, nlat, m_off=0, mode=None):
     """spectrum [L, Mloc, BC] -> xf [Mloc, nlat, BC]."""
     _need_cuda(c, table)
     assert c.is_contiguous() and c.dtype == torch.complex64 and table.dtype == torch.float32
@@ -124,8 +161,13 @@ def legendre_inv_raw(c, table, nlat, m_off=0):
     mg, lt, kp = table.shape
     assert lt == lmax and kp == legendre_kpad(nlat), "Legendre table does not match the operand"
     xf = torch.empty(mloc, nlat, bc, dtype=torch.complex64, device=c.device)
-    _lib.check(_lib.load().mk_legendre_inv(c.data_ptr(), table.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
-                                           m_off, mg, _stream()), "mk_legendre_inv")
+    if _gemm_mode(mode) == "bf16x3":
+        img = legendre_x3_image(table, nlat, 1)
+        _lib.check(_lib.load().mk_legendre_inv_x3(c.data_ptr(), img.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
+                                                  m_off, mg, _stream()), "mk_legendre_inv_x3")
+    else:
+        _lib.check(_lib.load().mk_legendre_inv(c.data_ptr(), table.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
+                                               m_off, mg, _stream()), "mk_legendre_inv")
     return xf
 
 
@@ -156,38 +198,45 @@ def _w_phys(w):
     return wp if wp.is_contiguous() else wp.contiguous()
 
 
-def dhconv_fwd_raw(x, w_phys, batch, l_off=0, m_off=0):
+def _dh_fn(name, mode, cin, cout):
+    """bf16x3 kernels need even channel counts; odd ones take the fp32 MFMA kernels."""
+    if _gemm_mode(mode) == "bf16x3" and cin % 2 == 0 and cout % 2 == 0:
+        name += "_x3"
+    return getattr(_lib.load(), name), name
+
+
+def dhconv_fwd_raw(x, w_phys, batch, l_off=0, m_off=0, mode=None):
     _need_cuda(x, w_phys)
     assert x.is_contiguous() and x.dtype == torch.complex64 and w_phys.is_contiguous() and w_phys.dtype == torch.complex64
     lloc, mloc, bc = x.shape
     l2, cin, cout = w_phys.shape
     assert l2 == lloc and bc == batch * cin, "dhconv operand shapes do not match"
     y = torch.empty(lloc, mloc, batch * cout, dtype=torch.complex64, device=x.device)
-    _lib.check(_lib.load().mk_dhconv_fwd(x.data_ptr(), w_phys.data_ptr(), y.data_ptr(), lloc, mloc, batch, cin, cout,
-                                         l_off, m_off, _stream()), "mk_dhconv_fwd")
+    fn, name = _dh_fn("mk_dhconv_fwd", mode, cin, cout)
+    _lib.check(fn(x.data_ptr(), w_phys.data_ptr(), y.data_ptr(), lloc, mloc, batch, cin, cout, l_off, m_off, _stream()), name)
     return y
 
 
-def dhconv_dgrad_raw(gy, w_phys, batch, l_off=0, m_off=0):
+def dhconv_dgrad_raw(gy, w_phys, batch, l_off=0, m_off=0, mode=None):
     _need_cuda(gy, w_phys)
     assert gy.is_contiguous() and gy.dtype == torch.complex64 and w_phys.is_contiguous()
     lloc, mloc, bo = gy.shape
     l2, cin, cout = w_phys.shape
     assert l2 == lloc and bo == batch * cout
     gx = torch.empty(lloc, mloc, batch * cin, dtype=torch.complex64, device=gy.device)
-    _lib.check(_lib.load().mk_dhconv_dgrad(gy.data_ptr(), w_phys.data_ptr(), gx.data_ptr(), lloc, mloc, batch, cin,
-                                           cout, l_off, m_off, _stream()), "mk_dhconv_dgrad")
+    fn, name = _dh_fn("mk_dhconv_dgrad", mode, cin, cout)
+    _lib.check(fn(gy.data_ptr(), w_phys.data_ptr(), gx.data_ptr(), lloc, mloc, batch, cin, cout, l_off, m_off, _stream()), name)
     return gx
 
 
-def dhconv_wgrad_raw(x, gy, batch, l_off=0, m_off=0):
+def dhconv_wgrad_raw(x, gy, batch, l_off=0, m_off=0, mode=None):
     _need_cuda(x, gy)
     assert x.is_contiguous() and gy.is_contiguous() and x.dtype == torch.complex64 and gy.dtype == torch.complex64
     lloc, mloc, bi = x.shape
     cin, cout = bi // batch, gy.shape[2] // batch
     gw = torch.empty(lloc, cin, cout, dtype=torch.complex64, device=x.device)
-    _lib.check(_lib.load().mk_dhconv_wgrad(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), lloc, mloc, batch, cin, cout,
-                                           l_off, m_off, _stream()), "mk_dhconv_wgrad")
+    fn, name = _dh_fn("mk_dhconv_wgrad", mode, cin, cout)
+    _lib.check(fn(x.data_ptr(), gy.data_ptr(), gw.data_ptr(), lloc, mloc, batch, cin, cout, l_off, m_off, _stream()), name)
     return gw
 
 
@@ -235,14 +284,13 @@ class _LegendreFwd(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, xf, table, lmax, m_off):
-        ctx.save_for_backward(table)
+        ctx.table = table   # constant buffer; the python object carries the cached bf16x3 images
         ctx.nlat, ctx.m_off = xf.shape[1], m_off
         return legendre_fwd_raw(xf, table, lmax, m_off)
 
     @staticmethod
     def backward(ctx, gc):
-        (table,) = ctx.saved_tensors
-        return legendre_inv_raw(gc.contiguous(), table, ctx.nlat, ctx.m_off), None, None, None
+        return legendre_inv_raw(gc.contiguous(), ctx.table, ctx.nlat, ctx.m_off), None, None, None
 
 
 class _LegendreInv(torch.autograd.Function):
@@ -250,14 +298,13 @@ class _LegendreInv(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, c, table, nlat, m_off):
-        ctx.save_for_backward(table)
+        ctx.table = table
         ctx.lmax, ctx.m_off = c.shape[0], m_off
         return legendre_inv_raw(c, table, nlat, m_off)
 
     @staticmethod
     def backward(ctx, gxf):
-        (table,) = ctx.saved_tensors
-        return legendre_fwd_raw(gxf.contiguous(), table, ctx.lmax, ctx.m_off), None, None, None
+        return legendre_fwd_raw(gxf.contiguous(), ctx.table, ctx.lmax, ctx.m_off), None, None, None
 
 
 class _SpecPack(torch.autograd.Function):

@@ -116,14 +116,18 @@ LEG_CASES = [  # grid, nlat, lmax, mmax, bc
 ]
 
 
+GEMM_MODES = ["bf16x3", "f32"]   # bf16 MFMA with exact 3-way operand split (default) / fp32 MFMA
+
+
+@pytest.mark.parametrize("mode", GEMM_MODES)
 @pytest.mark.parametrize("grid,nlat,lmax,mmax,bc", LEG_CASES)
-def test_legendre_fwd_inv(dev, grid, nlat, lmax, mmax, bc):
+def test_legendre_fwd_inv(dev, grid, nlat, lmax, mmax, bc, mode):
     from makani_amd import ops
     rng = np.random.default_rng(7)
     tabw = ops.legendre_table(grid, nlat, lmax, mmax, True)
     tabp = ops.legendre_table(grid, nlat, lmax, mmax, False)
     xf = (rng.standard_normal((mmax, nlat, bc)) + 1j * rng.standard_normal((mmax, nlat, bc))).astype(np.complex64)
-    c = ops.legendre_fwd_raw(torch.from_numpy(xf).to(dev), tabw.to(dev), lmax)
+    c = ops.legendre_fwd_raw(torch.from_numpy(xf).to(dev), tabw.to(dev), lmax, mode=mode)
     W = tabw.numpy()[:, :, :nlat].astype(np.float64)
     want = np.einsum("mlk,mkn->lmn", W, xf.astype(np.complex128))
     mask = tril_mask(lmax, mmax)[:, :, None]
@@ -131,13 +135,15 @@ def test_legendre_fwd_inv(dev, grid, nlat, lmax, mmax, bc):
     assert rel(got, want) < TOL
     # synthesis: entries with l < m must be ignored whatever they hold
     cin = (rng.standard_normal((lmax, mmax, bc)) + 1j * rng.standard_normal((lmax, mmax, bc))).astype(np.complex64)
-    y = ops.legendre_inv_raw(torch.from_numpy(cin).to(dev), tabp.to(dev), nlat)
+    cin = np.where(mask, cin, np.complex64(complex(np.nan, np.nan)))
+    y = ops.legendre_inv_raw(torch.from_numpy(cin).to(dev), tabp.to(dev), nlat, mode=mode)
     P = tabp.numpy()[:, :, :nlat].astype(np.float64)
     wanty = np.einsum("mlk,lmn->mkn", P, np.where(mask, cin, 0).astype(np.complex128))
     assert rel(y.cpu().numpy(), wanty) < TOL
 
 
-def test_legendre_mode_shard(dev):
+@pytest.mark.parametrize("mode", GEMM_MODES)
+def test_legendre_mode_shard(dev, mode):
     """m-sharded launch (w-parallel tables): local modes [m_off, m_off + mloc)."""
     from makani_amd import ops
     rng = np.random.default_rng(8)
@@ -145,14 +151,14 @@ def test_legendre_mode_shard(dev):
     tabw = ops.legendre_table(grid, nlat, lmax, mmax, True).to(dev)
     tabp = ops.legendre_table(grid, nlat, lmax, mmax, False).to(dev)
     xf = torch.from_numpy((rng.standard_normal((mmax, nlat, bc)) + 1j * rng.standard_normal((mmax, nlat, bc))).astype(np.complex64)).to(dev)
-    full = ops.legendre_fwd_raw(xf, tabw, lmax)
+    full = ops.legendre_fwd_raw(xf, tabw, lmax, mode=mode)
     m_off, mloc = 9, 11
-    part = ops.legendre_fwd_raw(xf[m_off:m_off + mloc].contiguous(), tabw, lmax, m_off)
+    part = ops.legendre_fwd_raw(xf[m_off:m_off + mloc].contiguous(), tabw, lmax, m_off, mode=mode)
     mask = torch.from_numpy(tril_mask(lmax, mloc, 0, m_off)).to(dev)[:, :, None]
     assert torch.equal(torch.where(mask, part, 0), torch.where(mask, full[:, m_off:m_off + mloc], 0))
     cfull = torch.where(torch.from_numpy(tril_mask(lmax, mmax)).to(dev)[:, :, None], full, 0)
-    yfull = ops.legendre_inv_raw(cfull, tabp, nlat)
-    ypart = ops.legendre_inv_raw(cfull[:, m_off:m_off + mloc].contiguous(), tabp, nlat, m_off)
+    yfull = ops.legendre_inv_raw(cfull, tabp, nlat, mode=mode)
+    ypart = ops.legendre_inv_raw(cfull[:, m_off:m_off + mloc].contiguous(), tabp, nlat, m_off, mode=mode)
     assert torch.equal(ypart, yfull[m_off:m_off + mloc])
 
 
@@ -216,6 +222,8 @@ DH_CASES = [  # L, M, B, I, O, l_off, m_off
     (10, 21, 2, 16, 12, 20, 0),    # l shard (h-parallel)
     (30, 11, 1, 12, 16, 0, 15),    # m shard (w-parallel): low degrees have no valid mode
     (70, 71, 1, 72, 130, 0, 0),    # > 1 column tile, ragged
+    (140, 141, 1, 8, 10, 0, 0),    # > 128 rows (m, b): two row tiles of the bf16x3 engine
+    (9, 10, 2, 136, 70, 0, 0),     # > 128 input channels: two wgrad row tiles
 ]
 
 
@@ -226,8 +234,9 @@ def _dh_ref(x, w, l_off, m_off):
     return np.where(mask, y, 0), mask
 
 
+@pytest.mark.parametrize("mode", GEMM_MODES)
 @pytest.mark.parametrize("L,M,B,I,O,l_off,m_off", DH_CASES)
-def test_dhconv_fwd_bwd(dev, L, M, B, I, O, l_off, m_off):
+def test_dhconv_fwd_bwd(dev, L, M, B, I, O, l_off, m_off, mode):
     from makani_amd import ops
     rng = np.random.default_rng(21)
 
@@ -238,15 +247,15 @@ def test_dhconv_fwd_bwd(dev, L, M, B, I, O, l_off, m_off):
     want, mask = _dh_ref(x, w, l_off, m_off)
     wphys = torch.from_numpy(np.ascontiguousarray(w.transpose(2, 0, 1))).to(dev)
     xd = torch.from_numpy(x.reshape(L, M, B * I)).to(dev)
-    y = ops.dhconv_fwd_raw(xd, wphys, B, l_off, m_off).cpu().numpy().reshape(L, M, B, O)
+    y = ops.dhconv_fwd_raw(xd, wphys, B, l_off, m_off, mode=mode).cpu().numpy().reshape(L, M, B, O)
     assert rel(np.where(mask, y, 0), want) < TOL
     # dgrad / wgrad against the analytic adjoints (torch convention: conj on the other operand)
     gyd = torch.from_numpy(gy.reshape(L, M, B * O)).to(dev)
     gym = np.where(mask, gy, 0).astype(np.complex128)
-    gx = ops.dhconv_dgrad_raw(gyd, wphys, B, l_off, m_off).cpu().numpy().reshape(L, M, B, I)
+    gx = ops.dhconv_dgrad_raw(gyd, wphys, B, l_off, m_off, mode=mode).cpu().numpy().reshape(L, M, B, I)
     want_gx = np.einsum("lmbo,iol->lmbi", gym, np.conj(w).astype(np.complex128))
     assert rel(np.where(mask, gx, 0), want_gx) < TOL
-    gw = ops.dhconv_wgrad_raw(xd, gyd, B, l_off, m_off).cpu().numpy()  # [L,I,O]
+    gw = ops.dhconv_wgrad_raw(xd, gyd, B, l_off, m_off, mode=mode).cpu().numpy()  # [L,I,O]
     want_gw = np.einsum("lmbi,lmbo->lio", np.conj(np.where(mask, x, 0)).astype(np.complex128), gym)
     assert rel(gw, want_gw) < TOL
 

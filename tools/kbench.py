@@ -58,7 +58,7 @@ def main():
         else:
             ach, peak, u = work / (ms * 1e-3) / 1e9, PEAK_GB, "GB/s"
         rows.append((name, shape, ms, best, ach, u, ach / peak))
-        print(f"{name:14s} {shape:22s} {ms:8.3f} ms (min {best:7.3f})  {ach:9.1f} {u:8s} {100 * ach / peak:5.1f}% of peak",
+        print(f"{name:22s} {shape:22s} {ms:8.3f} ms (min {best:7.3f})  {ach:9.1f} {u:8s} {100 * ach / peak:5.1f}% of peak",
               flush=True)
 
     for (grid, K, N) in (("equiangular", 721, 1440), ("legendre-gauss", 240, 480)):
@@ -82,12 +82,13 @@ def main():
         tabw = ops.legendre_table(grid, K, L, M, True).to(dev)
         c = ops.legendre_fwd_raw(xf, tabw, L)
         leg_flop = 4.0 * T * K * bc
-        if not only or "legendre_fwd" in only:
-            ms, b = timeit(lambda: ops.legendre_fwd_raw(xf, tabw, L), args.iters)
-            report("legendre_fwd", shape, ms, b, leg_flop, "flop")
-        if not only or "legendre_inv" in only:
-            ms, b = timeit(lambda: ops.legendre_inv_raw(c, tabw, K), args.iters)
-            report("legendre_inv", shape, ms, b, leg_flop, "flop")
+        for mode in ("f32", "bf16x3"):
+            if not only or "legendre_fwd" in only:
+                ms, b = timeit(lambda: ops.legendre_fwd_raw(xf, tabw, L, mode=mode), args.iters)
+                report(f"legendre_fwd[{mode}]", shape, ms, b, leg_flop, "flop")
+            if not only or "legendre_inv" in only:
+                ms, b = timeit(lambda: ops.legendre_inv_raw(c, tabw, K, mode=mode), args.iters)
+                report(f"legendre_inv[{mode}]", shape, ms, b, leg_flop, "flop")
         del x, xb, xf, tabw, c
 
     E, B = args.bc, args.batch
@@ -96,15 +97,16 @@ def main():
     gy = torch.randn(L, M, B * E, dtype=torch.complex64, device=dev)
     flop = 8.0 * E * E * T * B
     shape = f"L{L} M{M} B{B} E{E}"
-    if not only or "dhconv_fwd" in only:
-        ms, b = timeit(lambda: ops.dhconv_fwd_raw(xs, w, B), args.iters)
-        report("dhconv_fwd", shape, ms, b, flop, "flop")
-    if not only or "dhconv_dgrad" in only:
-        ms, b = timeit(lambda: ops.dhconv_dgrad_raw(gy, w, B), args.iters)
-        report("dhconv_dgrad", shape, ms, b, flop, "flop")
-    if not only or "dhconv_wgrad" in only:
-        ms, b = timeit(lambda: ops.dhconv_wgrad_raw(xs, gy, B), args.iters)
-        report("dhconv_wgrad", shape, ms, b, flop, "flop")
+    for mode in ("f32", "bf16x3"):
+        if not only or "dhconv_fwd" in only:
+            ms, b = timeit(lambda: ops.dhconv_fwd_raw(xs, w, B, mode=mode), args.iters)
+            report(f"dhconv_fwd[{mode}]", shape, ms, b, flop, "flop")
+        if not only or "dhconv_dgrad" in only:
+            ms, b = timeit(lambda: ops.dhconv_dgrad_raw(gy, w, B, mode=mode), args.iters)
+            report(f"dhconv_dgrad[{mode}]", shape, ms, b, flop, "flop")
+        if not only or "dhconv_wgrad" in only:
+            ms, b = timeit(lambda: ops.dhconv_wgrad_raw(xs, gy, B, mode=mode), args.iters)
+            report(f"dhconv_wgrad[{mode}]", shape, ms, b, flop, "flop")
 
 
 if __name__ == "__main__":
