@@ -21,9 +21,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WT = 256;          // threads (4 waves, 2 x 2)
-constexpr int WTI = 128, WTK = 64;            // workgroup tile: (64 * MT) o  x  128 i, k-step 64
-constexpr int WPITCH = WTK * 2 + 16;          // bytes per LDS row: 128 data + 16 pad
-constexpr int WTILE_BYTES = WTI * WPITCH;     // a 128-row operand tile
+constexpr int WTI = 128;                      // workgroup tile: (64 * MT) o  x  128 i, k-step TK pixels (template)
 static int wgrad_target() { static int v = [] { const char* e = getenv("MK_WGRAD_TARGET"); return e ? atoi(e) : 1536; }(); return v; }
 #define MK_WGRAD_TARGET wgrad_target()
 
@@ -37,32 +35,35 @@ struct WgradParams {
     int slab;                   // pixels per slab (multiple of 64)
 };
 
-// (128 * NV / 4) rows x 64 k bf16 tile: NV 16-byte vectors per thread
-template <int NV>
+// (NV * 256 / WVPR) rows x TK k bf16 tile: NV 16-byte vectors per thread, WVPR = TK / 8 vectors per row,
+// LDS row pitch WPITCH = 2 TK + 16 bytes (an odd number of 16-byte units: conflict-free ds_read_b128)
+template <int NV, int WVPR>
 __device__ __forceinline__ void wg_load(const __hip_bfloat16* base, long long ld, int rows_valid, long long k0,
                                         long long kend, uint4 (&r)[NV], int tid) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * WT;
-        const int row = v >> 3, c = v & 7;
+        const int row = v / WVPR, c = v % WVPR;
         const long long k = k0 + c * 8;
         r[i] = make_uint4(0u, 0u, 0u, 0u);
         if (row < rows_valid && k < kend) r[i] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
     }
 }
-template <int NV>
+template <int NV, int WVPR>
 __device__ __forceinline__ void wg_store(char* lds, const uint4 (&r)[NV], int tid) {
+    constexpr int WPITCH = WVPR * 16 + 16;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * WT;
-        const int row = v >> 3, c = v & 7;
+        const int row = v / WVPR, c = v % WVPR;
         *reinterpret_cast<uint4*>(lds + row * WPITCH + c * 16) = r[i];
     }
 }
 
-template <int MT>   // 32-row o-tiles per wave: workgroup tile (64 * MT) x 128
+template <int MT, int WTK>   // 32-row o-tiles per wave: workgroup tile (64 * MT) x 128; k-step in pixels
 __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
-    constexpr int WTO = 64 * MT, ATILE = WTO * WPITCH, BUF = ATILE + WTILE_BYTES, NVA = 2 * MT;
+    constexpr int WVPR = WTK / 8, WPITCH = WTK * 2 + 16, WTILE_BYTES = WTI * WPITCH;
+    constexpr int WTO = 64 * MT, ATILE = WTO * WPITCH, BUF = ATILE + WTILE_BYTES, NVA = WTO * WVPR / WT, NVB = WTI * WVPR / WT;
     extern __shared__ __attribute__((aligned(16))) char lds[];   // [2 buffers][A tile | B tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -91,20 +92,20 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    uint4 ra[NVA], rb[4];
+    uint4 ra[NVA], rb[NVB];
     const int nk = (int)((k_end - k_begin + WTK - 1) / WTK);
-    wg_load<NVA>(ga, p.P, ov, k_begin, k_end, ra, tid);
-    wg_load<4>(gb, p.P, iv, k_begin, k_end, rb, tid);
-    wg_store<NVA>(lds, ra, tid);
-    wg_store<4>(lds + ATILE, rb, tid);
+    wg_load<NVA, WVPR>(ga, p.P, ov, k_begin, k_end, ra, tid);
+    wg_load<NVB, WVPR>(gb, p.P, iv, k_begin, k_end, rb, tid);
+    wg_store<NVA, WVPR>(lds, ra, tid);
+    wg_store<NVB, WVPR>(lds + ATILE, rb, tid);
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         if (kt + 1 < nk) {
             const long long k0 = k_begin + (long long)(kt + 1) * WTK;
-            wg_load<NVA>(ga, p.P, ov, k0, k_end, ra, tid);
-            wg_load<4>(gb, p.P, iv, k0, k_end, rb, tid);
+            wg_load<NVA, WVPR>(ga, p.P, ov, k0, k_end, ra, tid);
+            wg_load<NVB, WVPR>(gb, p.P, iv, k0, k_end, rb, tid);
         }
         const char* As = lds + cur * BUF;
         const char* Bs = As + ATILE;
@@ -124,8 +125,8 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
                     acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
         }
         if (kt + 1 < nk) {
-            wg_store<NVA>(lds + (cur ^ 1) * BUF, ra, tid);
-            wg_store<4>(lds + (cur ^ 1) * BUF + ATILE, rb, tid);
+            wg_store<NVA, WVPR>(lds + (cur ^ 1) * BUF, ra, tid);
+            wg_store<NVB, WVPR>(lds + (cur ^ 1) * BUF + ATILE, rb, tid);
         }
         __syncthreads();
     }
@@ -176,11 +177,14 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     const long long nslab_tot = (long long)p.nslab * batch;
     const long long grid = ((nslab_tot + 7) / 8) * 8 * p.nblk_o * p.nblk_i;
     MK_REQUIRE(grid < 2147483647LL, "grid too large");
-    const size_t lds = 2 * (size_t)(WTO * WPITCH + WTILE_BYTES);
-    if (MT == 4)
-        hipLaunchKernelGGL(conv1x1_wgrad_kernel<4>, dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
-    else
-        hipLaunchKernelGGL(conv1x1_wgrad_kernel<2>, dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
+    static const int tk = [] { const char* e = getenv("MK_WGRAD_TK"); return e ? atoi(e) : 64; }();
+    if (tk == 32) {
+        const size_t lds = 2 * (size_t)((WTO + WTI) * (32 * 2 + 16));
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 32>), dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
+    } else {
+        const size_t lds = 2 * (size_t)((WTO + WTI) * (64 * 2 + 16));
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64>), dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
+    }
     MK_LAUNCH_CHECK();
     return 0;
 }

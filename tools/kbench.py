@@ -107,6 +107,24 @@ def main():
         if not only or "dhconv_wgrad" in only:
             ms, b = timeit(lambda: ops.dhconv_wgrad_raw(xs, gy, B, mode=mode), args.iters)
             report(f"dhconv_wgrad[{mode}]", shape, ms, b, flop, "flop")
+    if not only or "conv_wgrad" in only:
+        from makani_amd import _lib
+        for (O, I, P) in ((768, 384, 115200), (384, 768, 115200), (384, 384, 115200), (768, 384, 1038240),
+                          (384, 768, 1038240), (384, 384, 1038240)):
+            gyb = torch.randn(1, O, P, device=dev).to(torch.bfloat16)
+            xb2 = torch.randn(1, I, P, device=dev).to(torch.bfloat16)
+            gw = torch.zeros(O, I, device=dev)
+            fn = _lib.load().mk_conv1x1_wgrad
+
+            def run():
+                _lib.check(fn(gyb.data_ptr(), xb2.data_ptr(), gw.data_ptr(), 1, O, I, P, ops._stream()), "mk_conv1x1_wgrad")
+            ms, b = timeit(run, args.iters)
+            rows.append(("conv_wgrad", f"{O}x{I}x{P}", ms, b))
+            tf = 2.0 * O * I * P / (ms * 1e-3) / 1e12
+            gb = 2.0 * (O + I) * P / (ms * 1e-3) / 1e9
+            print(f"{'conv1x1_wgrad':22s} {f'{O}x{I}x{P}':22s} {ms:8.3f} ms (min {b:7.3f})  {tf:9.1f} TFLOP/s bf16  {gb:8.1f} GB/s unique",
+                  flush=True)
+            del gyb, xb2, gw
 
 
 if __name__ == "__main__":

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round measurement set (run on the GPU box from the repo root): bench line, rocprofv3 kernel stats, PMC traffic.
+# usage: bash tools/measure.sh <tag>      -> gpurun_out/<tag>_bench.json, gpurun_out/<tag>_prof/, gpurun_out/<tag>_traffic/
+set -o pipefail
+tag=${1:-rXX}
+export TMPDIR=/tmp
+out=gpurun_out
+timeout -k 10 500 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
+tail -1 $out/${tag}_bench.json | cut -c1-400
+rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o runc -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing > $out/${tag}_prof.log 2>&1 || exit 2
+echo "kernel trace done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c -d $out/${tag}_traffic/pmc_$c -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/${tag}_pmc_$c.log 2>&1 || exit 3
+  echo "pmc $c done"
+done

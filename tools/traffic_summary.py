@@ -16,14 +16,25 @@ import sys
 from collections import defaultdict
 
 NAMES = [("irfft", "irfft_split_kernel"), ("irfft", "irfft_kernel"), ("rfft", "rfft_split_kernel"), ("rfft", "rfft_kernel"),
+         ("legendre_fwd", "legendre_fwd_x3_kernel"), ("legendre_inv", "legendre_inv_x3_kernel"),
+         ("dhconv_fwd", "dhconv_fwd_x3_kernel"), ("dhconv_dgrad", "dhconv_dgrad_x3_kernel"),
+         ("dhconv_wgrad", "dhconv_wgrad_x3_kernel"),
          ("legendre_fwd", "legendre_fwd_kernel"), ("legendre_inv", "legendre_inv_kernel"),
          ("dhconv_fwd", "dhconv_fwd_kernel"), ("dhconv_dgrad", "dhconv_dgrad_kernel"),
-         ("dhconv_wgrad", "dhconv_wgrad_kernel"), ("bias_gelu_fwd", "bias_gelu_fwd_kernel"),
+         ("dhconv_wgrad", "dhconv_wgrad_kernel"), ("conv1x1_wgrad", "conv1x1_wgrad_kernel"), ("bias_gelu_fwd", "bias_gelu_fwd_kernel"),
          ("bias_gelu_bwd", "bias_gelu_bwd_kernel"), ("instnorm", "instnorm_"), ("instnorm", "rowsum2_kernel")]
 
 
 def collect(d, counter):
     acc = defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*_results.db"), recursive=True):   # rocprofv3's default rocpd output
+        import sqlite3
+        cur = sqlite3.connect(f).cursor()
+        for kname, val in cur.execute("select kernel_name, value from counters_collection where counter_name = ?", (counter,)):
+            for short, pat in NAMES:
+                if pat in kname:
+                    acc[short].append(float(val))
+                    break
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
