@@ -174,6 +174,14 @@ int mk_instnorm_bwd(const void* x, const void* gy, const float* stats, const flo
 int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
                      void* stream);
 
+/* Forward / data-gradient GEMM of the same convolution on bf16 NCHW fields:
+ *   y[b][m][p] = sum_k a[m][k] * x[b][k][p] (+ addend[b][m][p], may be NULL),   fp32 accumulation, one rounding.
+ * a = W [O][I] for the forward pass (m = o, k = i), a = W^T [I][O] for the data gradient.  Replaces the
+ * F.conv2d(x, w) of nn.Conv2d(.., 1) (layers.py:95-99,158-206) and its input gradient; the skip additions of
+ * the FNO block (sfnonet.py:219-246) ride in `addend`.  K and P must be multiples of 8. */
+int mk_conv1x1_fwd(const void* a, const void* x, const void* addend, void* y, int batch, int M, int K,
+                   long long P, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

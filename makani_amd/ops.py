@@ -240,6 +240,27 @@ def dhconv_wgrad_raw(x, gy, batch, l_off=0, m_off=0, mode=None):
     return gw
 
 
+def conv1x1_supported(x3, a):
+    """bf16 [B, K, P] field and [M, K] matrix with 16-byte aligned rows."""
+    return (x3.is_cuda and x3.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and x3.shape[1] % 8 == 0
+            and x3.shape[2] % 8 == 0)
+
+
+def conv1x1_fwd_raw(a, x3, addend=None):
+    """y[b] = a @ x3[b] (+ addend[b]):  a [M, K] bf16, x3 [B, K, P] bf16 -> [B, M, P] bf16 (HIP bf16 MFMA GEMM)."""
+    _need_cuda(a, x3)
+    assert a.is_contiguous() and x3.is_contiguous() and a.dtype == torch.bfloat16 and x3.dtype == torch.bfloat16
+    b, k, p = x3.shape
+    m = a.shape[0]
+    assert a.shape[1] == k
+    if addend is not None:
+        assert addend.is_contiguous() and addend.dtype == torch.bfloat16 and tuple(addend.shape) == (b, m, p)
+    y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
+    _lib.check(_lib.load().mk_conv1x1_fwd(a.data_ptr(), x3.data_ptr(), addend.data_ptr() if addend is not None else None,
+                                          y.data_ptr(), b, m, k, p, _stream()), "mk_conv1x1_fwd")
+    return y
+
+
 # ----------------------------------------------------------------------------
 # differentiable operators (all linear in the data: backward = adjoint launch)
 # ----------------------------------------------------------------------------

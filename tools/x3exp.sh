@@ -1,1 +1,2 @@
-for tk in 64 32; do for tg in 1536 3072; do echo "== TK=$tk TARGET=$tg"; MK_WGRAD_TK=$tk MK_WGRAD_TARGET=$tg timeout -k 10 200 python tools/kbench.py --only conv_wgrad --iters 10 2>&1 | grep conv1x1; done; done
+timeout -k 10 300 python -m pytest tests/test_kernels_gpu.py -x -q -k "conv1x1_fwd" 2>&1 | tail -15
+timeout -k 10 200 python tools/kbench.py --only conv_fwd --iters 10 2>&1 | grep conv1x1
