@@ -253,10 +253,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torchrun with {args.gpus} ranks (WORLD_SIZE={world})")
+    # rehearsal hooks (one-GPU box): MK_BENCH_BACKEND=gloo MK_BENCH_ONE_DEVICE=1 run every rank on cuda:0 over gloo,
+    # which exercises this script's whole N > 1 path except the RCCL wire.  The driver's runs use neither.
     if world > 1:
-        comm.init(model_parallel_sizes=[world, 1, 1, 1], model_parallel_names=["h", "w", "fin", "fout"])
+        comm.init(model_parallel_sizes=[world, 1, 1, 1], model_parallel_names=["h", "w", "fin", "fout"],
+                  backend=os.environ.get("MK_BENCH_BACKEND", "nccl"))
     rank = comm.get_world_rank()
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if os.environ.get("MK_BENCH_ONE_DEVICE") == "1" else int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     hsize, hrank = comm.get_size("h"), comm.get_rank("h")

@@ -22,7 +22,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int WT = 256;          // threads (4 waves, 2 x 2)
 constexpr int WTI = 128;                      // workgroup tile: (64 * MT) o  x  128 i, k-step TK pixels (template)
-static int wgrad_target() { static int v = [] { const char* e = getenv("MK_WGRAD_TARGET"); return e ? atoi(e) : 1536; }(); return v; }
+static int wgrad_target() { static int v = [] { const char* e = getenv("MK_WGRAD_TARGET"); return e ? atoi(e) : 0; }(); return v; }
 #define MK_WGRAD_TARGET wgrad_target()
 
 struct WgradParams {
@@ -336,10 +336,31 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     const int WTO = 64 * MT;
     p.nblk_o = mk::ceil_div(cout, WTO);
     p.nblk_i = mk::ceil_div(cin, WTI);
-    // slab length: enough workgroups to fill the chip (>= ~1500), at least 512 pixels each
+    // Slab count.  All blocks of a slab run on one XCD (32 CUs x 2 workgroups = 64 slots) and the slabs are dealt
+    // round-robin to the 8 XCDs: take s slabs per XCD so that s * (blocks per slab) just fills w rounds of 64 slots
+    // (w <= 4, fewest rounds among the well-filled choices).  Measured on 768x384 / 384x384 blocks: 56 slabs
+    // (2 x 63 and 1 x 63 of 64 slots) beat the earlier ">= 1536 workgroups" rule by 17-25 %, 28 or 86 slabs lose
+    // to the partly empty last round.  MK_WGRAD_TARGET (> 0) restores the workgroup-count rule.
     {
-        const long long nblk = (long long)p.nblk_o * p.nblk_i * batch;
-        long long want = (MK_WGRAD_TARGET + nblk - 1) / nblk;   // slabs per batch item
+        const long long nblk1 = (long long)p.nblk_o * p.nblk_i;
+        long long want;   // slabs per batch item
+        if (MK_WGRAD_TARGET > 0) {
+            want = (MK_WGRAD_TARGET + nblk1 * batch - 1) / (nblk1 * batch);
+        } else {
+            long long best_s = 1;
+            double best = -1.0;
+            for (int w = 1; w <= 4; ++w) {
+                const long long sx = (64LL * w) / nblk1;
+                if (sx < 1) continue;
+                const double score = (double)(sx * nblk1) / (64.0 * w) - 0.03 * w;
+                if (score > best) {
+                    best = score;
+                    best_s = sx;
+                }
+            }
+            want = (8 * best_s + batch - 1) / batch;
+            if (want < 1) want = 1;
+        }
         long long slab = (P + want - 1) / want;
         slab = (slab + 63) / 64 * 64;
         if (slab < 512) slab = 512;

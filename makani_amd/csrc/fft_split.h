@@ -22,6 +22,14 @@ constexpr int SNSUB = 24;      // sub-rows per workgroup
 constexpr int STHREADS = 384;  // 16 lanes per sub-row
 constexpr int SLDS_F2 = SNSUB * SP + 96;
 
+// Schedule index -> tile.  Tiles t and t + 1 (adjacent channel groups of one latitude) share the 128-byte
+// lines of xf[m][k][:] (a tile covers 64 or 192 bytes per mode): run them on the same XCD (schedule index
+// mod 8) back to back, so each line is fetched from / merged for HBM once instead of once per XCD.
+__device__ __forceinline__ int pair_tile(int i) {
+    const int xcd = i & 7, seq = i >> 3;
+    return ((((seq >> 1) << 3) + xcd) << 1) + (seq & 1);
+}
+
 __device__ __forceinline__ int sub_base(int sr, int S) { return sr * SP + 4 * (sr / S); }
 __device__ __forceinline__ int phi(int i) { return i + (i >> 4); }
 // an opaque copy of a value: stops the compiler from hoisting per-tile index arithmetic out of the
@@ -89,22 +97,24 @@ template <> struct InVec<__hip_bfloat16> {
 template <int S, typename TIn>
 __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restrict__ x, float2* __restrict__ xf,
                                                               const float2* __restrict__ tw, int BC, int K, int M,
-                                                              float scale0, float scale_m, float scale_h) {
+                                                              float scale0, float scale_m, float scale_h, int exp) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2, E = InVec<TIn>::E;
     // staging unit: S consecutive vectors of E reals = E reals (E/2 complex) of every sub-sequence
     constexpr int GPR = N / (S * E), NGRP = G * GPR, IT = (NGRP + STHREADS - 1) / STHREADS;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
     const int ntile = (BC + G - 1) / G;
-    const int k = blockIdx.x / ntile;
-    const int bc0 = (blockIdx.x - k * ntile) * G;
+    const int tile = pair_tile(blockIdx.x);
+    if (tile >= ntile * K) return;
+    const int k = tile / ntile;
+    const int bc0 = (tile - k * ntile) * G;
 
     float vals[IT][S][E];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int v = tid + it * STHREADS;
         const int g = v / GPR, p = v - g * GPR;
-        const bool ok = (v < NGRP) && (bc0 + g < BC);
+        const bool ok = (v < NGRP) && (bc0 + g < BC) && !(exp & 1);
 #pragma unroll
         for (int c = 0; c < S; ++c) {
             if (ok) {
@@ -144,8 +154,9 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
         }
     }
     __syncthreads();
-    split_passes(lds, tid, S, tw15);
+    if (!(exp & 2)) split_passes(lds, tid, S, tw15);
     __syncthreads();
+    if (exp & 8) return;
 
     // mode split + radix-S combine, modes m and 240 - m together (they share Z[m], Z[240 - m]):
     //   F[m]     = e - i p,  F[240-m] = conj(e) - i conj(p),  e = (a + conj b)/2, p = w_m (a - conj b)/2
@@ -179,6 +190,9 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
             }
             acc0 = cadd(acc0, f0);
             acc1 = cadd(acc1, f1);
+        }
+        if (exp & 4) {   // ablation: keep the arithmetic alive, store (almost) nothing
+            if (acc0.x + acc1.x != 12345.678f) continue;
         }
         if (mp < M) {
             const float sc = (mp == 0) ? scale0 : scale_m;
@@ -218,8 +232,15 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
     const int ntile = (BC + G - 1) / G;
     const int total = ntile * K;
     const float2* tw2 = tw + HH;
-    int tile = blockIdx.x;          // persistent: this workgroup walks tiles tile, tile + gridDim.x, ...
-    if (tile >= total) return;
+    // persistent: this workgroup walks the schedule indices blockIdx.x, + gridDim.x, ... (tiles via pair_tile)
+    const int total16 = (total + 15) & ~15;
+    auto next_valid = [&](int i) {
+        while (i < total16 && pair_tile(i) >= total) i += (int)gridDim.x;
+        return i;
+    };
+    int sched = next_valid(blockIdx.x);
+    if (sched >= total16) return;
+    int tile = pair_tile(sched);
 
     float2 tw15[15];
 #pragma unroll
@@ -285,8 +306,8 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
         }
     }
     __syncthreads();
-    const int next = tile + (int)gridDim.x;
-    if (next < total) gather(next, opaque(tid));
+    const int next = next_valid(sched + (int)gridDim.x);
+    if (next < total16) gather(pair_tile(next), opaque(tid));
     split_passes(lds, tl, S, tw15);
     __syncthreads();
 
@@ -323,8 +344,9 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
             }
         }
     }
-    if (next >= total) break;
-    tile = next;
+    if (next >= total16) break;
+    sched = next;
+    tile = pair_tile(next);
     __syncthreads();   // the image is rewritten by the next tile's merge step
   }
 }
@@ -341,22 +363,30 @@ static inline unsigned split_grid(long long tiles) {
         if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
         return v;
     }();
-    const long long cap = (long long)per_cu * cus;
-    return (unsigned)((per_cu > 0 && tiles > cap) ? cap : tiles);
+    const long long cap = (long long)per_cu * cus, t16 = (tiles + 15) / 16 * 16;
+    return (unsigned)((per_cu > 0 && t16 > cap) ? cap : t16);
+}
+
+// ablation switches for the forward kernel (MK_FFT_EXP): 1 no row loads, 2 no FFT passes, 4 no mode stores,
+// 8 stop after the passes -- wrong results, timing experiments only
+static inline int fft_exp() {
+    static const int v = [] { const char* e = getenv("MK_FFT_EXP"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 template <int S>
 int launch_rfft_split(const void* x, int x_dtype, float* xf, const float* tw, int bc, int nlat, int mmax, float s0,
                       float sm, float sh, hipStream_t st) {
     constexpr int G = SNSUB / S;
-    const dim3 grid((unsigned)(mk::ceil_div(bc, G) * nlat));   // one workgroup per tile (persistence costs it 70 VGPRs)
+    // one workgroup per tile (persistence costs it 70 VGPRs); rounded up to whole XCD pair groups
+    const dim3 grid((unsigned)((mk::ceil_div(bc, G) * nlat + 15) / 16 * 16));
     const size_t lds = sizeof(float2) * SLDS_F2;
     if (x_dtype == 0)
         hipLaunchKernelGGL((rfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float*)x, (float2*)xf,
-                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh, fft_exp());
     else
         hipLaunchKernelGGL((rfft_split_kernel<S, __hip_bfloat16>), grid, dim3(STHREADS), lds, st,
-                           (const __hip_bfloat16*)x, (float2*)xf, (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+                           (const __hip_bfloat16*)x, (float2*)xf, (const float2*)tw, bc, nlat, mmax, s0, sm, sh, fft_exp());
     return 0;
 }
 

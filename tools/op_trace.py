@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Which torch ops launch the small copy / fill / cast kernels of one training step (torch.profiler, one GPU)."""
+import os
+import sys
+from collections import defaultdict
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+from makani_amd import ops  # noqa: E402
+from makani_amd.optim import FusedAdam  # noqa: E402
+from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet  # noqa: E402
+
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+net = SphericalFourierNeuralOperatorNet(**bench.CONFIG).to(dev)
+opt = FusedAdam(net.parameters(), lr=1e-4)
+inp = torch.randn(1, 73, 721, 1440, device=dev)
+tar = torch.randn(1, 73, 721, 1440, device=dev)
+
+
+def step():
+    opt.zero_grad(set_to_none=True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        pred = net(inp)
+    loss = ((pred.float() - tar) ** 2).mean()
+    loss.backward()
+    opt.step()
+
+
+for _ in range(3):
+    step()
+torch.cuda.synchronize()
+from torch.profiler import ProfilerActivity, profile  # noqa: E402
+
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=False, record_shapes=True) as prof:
+    step()
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages(group_by_input_shape=True):
+    if e.device_time_total > 0 and e.count > 0:
+        rows.append((e.self_device_time_total, e.count, e.key, str(e.input_shapes)[:90]))
+rows.sort(reverse=True)
+for t, c, k, sh in rows[:int(os.environ.get('MK_TRACE_ROWS', '70'))]:
+    print(f"{t / 1e3:8.3f} ms  x{c:4d}  {k[:60]:60s} {sh}")
