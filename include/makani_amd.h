@@ -138,6 +138,16 @@ int mk_dhconv_dgrad_x3(const float* gy, const float* w, float* gx, int lloc, int
 int mk_dhconv_wgrad_x3(const float* x, const float* gy, float* gw, int lloc, int mloc, int batch,
                        int cin, int cout, int l_off, int m_off, void* stream);
 
+/* ---- "diagonal" spectral filter: one complex weight per (l, m) ---------------------------
+ * Public layout, P = L * M contiguous: x [B][I][P], w [I][O][P], y [B][O][P] complex64.
+ *   y[b][o][p] = sum_i x[b][i][p] * w[i][o][p]
+ * Replaces _contract_diagonal `einsum("bixy,ioxy->boxy")` (contractions.py:121-127) and its gradients
+ *   gx[b][i][p] = sum_o gy[b][o][p] * conj(w[i][o][p]),   gw[i][o][p] = sum_b conj(x[b][i][p]) * gy[b][o][p].
+ * Elementwise in p (1 flop per weight byte): HBM-streaming kernels, exact fp32 fma chains. */
+int mk_diag_fwd(const float* x, const float* w, float* y, int batch, int cin, int cout, long long P, void* stream);
+int mk_diag_dgrad(const float* gy, const float* w, float* gx, int batch, int cin, int cout, long long P, void* stream);
+int mk_diag_wgrad(const float* x, const float* gy, float* gw, int batch, int cin, int cout, long long P, void* stream);
+
 /* ---- layout conversion -------------------------------------------------- */
 /* torch [BC][L][M] complex64  <->  private [L][M][BC] complex64.  unpack writes
  * exact zeros where global l < m (what the reference's zero table entries give). */

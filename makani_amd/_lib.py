@@ -42,6 +42,9 @@ SIGNATURES = {
     "mk_dhconv_fwd_x3": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "mk_dhconv_dgrad_x3": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
     "mk_dhconv_wgrad_x3": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),
+    "mk_diag_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_diag_dgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_diag_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_spec_pack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _vp]),
     "mk_spec_unpack": (_c_int, [_vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_bias_gelu_fwd": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),

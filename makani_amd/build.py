@@ -7,7 +7,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmakani_amd.so")
-SOURCES = ["host.cpp", "fft.hip", "gemm.hip", "gemm_x3.hip", "layout.hip", "pointwise.hip", "conv_gemm.hip"]
+SOURCES = ["host.cpp", "fft.hip", "gemm.hip", "gemm_x3.hip", "layout.hip", "diag.hip", "pointwise.hip", "conv_gemm.hip"]
 HEADERS = ["common.h", "fft_split.h", os.path.join("..", "..", "include", "makani_amd.h")]
 
 

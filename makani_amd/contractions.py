@@ -8,8 +8,8 @@
 * ``dhconv`` complex (the SFNO filter, ``einsum("bixy,iox->boxy")``): HIP / fp32 MFMA
   (``mk_dhconv_*``), here wrapped with the layout conversion; ``SpectralConv`` uses the
   packed op directly and skips the conversions.
-* ``diagonal`` and the ``_real`` variants: secondary operator types (SURVEY 8a row 6;
-  unusable at the north-star size) -- evaluated with torch einsum on the device.
+* ``diagonal`` complex (unusable at the north-star size): HIP streaming kernels
+  (``mk_diag_*``) on the public layout.  The ``_real`` variants: torch einsum on the device.
 * separable variants: the reference's einsums name an output index ``o`` no operand
   carries and raise ``RuntimeError`` (contractions.py:139-152,169-178); so do these.
 """
@@ -34,6 +34,9 @@ def _contract_dhconv(ac, bc):
 
 
 def _contract_diagonal(ac, bc):
+    """``einsum("bixy,ioxy->boxy")`` (contractions.py:121-127): HIP streaming kernels for complex64 device operands."""
+    if ac.is_cuda and ac.dtype == torch.complex64 and bc.dtype == torch.complex64:
+        return ops.diag_contract(ac, bc)
     return torch.einsum("bixy,ioxy->boxy", ac, bc)
 
 

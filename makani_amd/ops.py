@@ -240,6 +240,46 @@ def dhconv_wgrad_raw(x, gy, batch, l_off=0, m_off=0, mode=None):
     return gw
 
 
+def _diag_launch(name, a, b, out, batch, cin, cout, p):
+    _lib.check(getattr(_lib.load(), name)(a.data_ptr(), b.data_ptr(), out.data_ptr(), batch, cin, cout, p, _stream()), name)
+    return out
+
+
+class _DiagContract(torch.autograd.Function):
+    """y[b,o,l,m] = sum_i x[b,i,l,m] w[i,o,l,m] on the public layout (mk_diag_*)."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        ctx.save_for_backward(x, w)
+        b, i, l, m = x.shape
+        o = w.shape[1]
+        y = torch.empty(b, o, l, m, dtype=torch.complex64, device=x.device)
+        return _diag_launch("mk_diag_fwd", x, w, y, b, i, o, l * m)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        b, i, l, m = x.shape
+        o = w.shape[1]
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _diag_launch("mk_diag_dgrad", gy, w, torch.empty_like(x), b, i, o, l * m)
+        if ctx.needs_input_grad[1]:
+            gw = _diag_launch("mk_diag_wgrad", x, gy, torch.empty_like(w), b, i, o, l * m)
+        return gx, gw
+
+
+def diag_contract(x, w):
+    """``einsum("bixy,ioxy->boxy")`` for complex64 x [B,I,L,M], w [I,O,L,M] on the HIP streaming kernels."""
+    _need_cuda(x, w)
+    if x.dtype != torch.complex64 or w.dtype != torch.complex64:
+        raise TypeError("diag_contract expects complex64 operands")
+    if x.dim() != 4 or w.dim() != 4 or x.shape[1] != w.shape[0] or tuple(x.shape[2:]) != tuple(w.shape[2:]):
+        raise ValueError(f"diag_contract: incompatible shapes {tuple(x.shape)} and {tuple(w.shape)}")
+    return _DiagContract.apply(x.contiguous(), w.contiguous())
+
+
 def conv1x1_supported(x3, a):
     """bf16 [B, K, P] field and [M, K] matrix with 16-byte aligned rows."""
     return (x3.is_cuda and x3.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and x3.shape[1] % 8 == 0

@@ -379,3 +379,25 @@ def test_conv1x1_fwd(dev, B, M, K, P, with_add):
     err = (y.float() - want).norm() / want.norm()
     assert err < 3e-3, err                                # one bf16 rounding of the result (2^-9 relative)
     assert (y.float() - want).abs().max() <= 2.0 ** -7 * want.abs().max()
+
+
+# --------------------------------------------------------------------------- diagonal filter contraction
+@pytest.mark.parametrize("B,I,O,L,M", [(2, 6, 5, 7, 8), (5, 3, 9, 16, 17), (1, 32, 32, 30, 31)])
+def test_diag_contract_fwd_bwd(dev, B, I, O, L, M):
+    """mk_diag_* vs the reference einsum `bixy,ioxy->boxy` (contractions.py:121-127) and its autograd gradients."""
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(11)
+
+    def crand(*s):
+        return torch.complex(torch.randn(*s, generator=g), torch.randn(*s, generator=g))
+
+    x, w, gy = crand(B, I, L, M), crand(I, O, L, M), crand(B, O, L, M)
+    xd, wd = x.to(dev).requires_grad_(True), w.to(dev).requires_grad_(True)
+    y = ops.diag_contract(xd, wd)
+    gx, gw = torch.autograd.grad(y, (xd, wd), gy.to(dev))
+    xr, wr = x.to(torch.complex128).requires_grad_(True), w.to(torch.complex128).requires_grad_(True)
+    yr = torch.einsum("bixy,ioxy->boxy", xr, wr)
+    gxr, gwr = torch.autograd.grad(yr, (xr, wr), gy.to(torch.complex128))
+    assert rel(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL
+    assert rel(gx.cpu().numpy(), gxr.numpy()) < TOL
+    assert rel(gw.cpu().numpy(), gwr.numpy()) < TOL
