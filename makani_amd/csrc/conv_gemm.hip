@@ -33,6 +33,7 @@ struct WgradParams {
     long long P;
     int nblk_o, nblk_i, nslab;  // nslab slabs per batch item
     int slab;                   // pixels per slab (multiple of 64)
+    int exp;                    // MK_WGRAD_EXP ablation: 1 = no atomic epilogue (wrong results)
 };
 
 // (NV * 256 / WVPR) rows x TK k bf16 tile: NV 16-byte vectors per thread, WVPR = TK / 8 vectors per row,
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = o0 + wr * 32 * MT + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (row < p.O && col < p.I) atomicAdd(&p.gw[(long long)row * p.I + col], acc[a][c][r]);
+                if (row < p.O && col < p.I && (!(p.exp & 1) || acc[a][c][r] == 12345.678f))
+                    atomicAdd(&p.gw[(long long)row * p.I + col], acc[a][c][r]);
             }
         }
 }
@@ -332,6 +334,8 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     p.I = cin;
     p.B = batch;
     p.P = P;
+    static const int wexp = [] { const char* e = getenv("MK_WGRAD_EXP"); return e ? atoi(e) : 0; }();
+    p.exp = wexp;
     const int MT = 2;   // 128 x 128 blocks (MT = 4: 256-row blocks at one workgroup per CU measured slower)
     const int WTO = 64 * MT;
     p.nblk_o = mk::ceil_div(cout, WTO);

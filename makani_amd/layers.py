@@ -53,11 +53,8 @@ class _PointwiseConv(torch.autograd.Function):
         if ctx.needs_input_grad[1] and x3.is_cuda and x3.dtype == torch.bfloat16 and gy.dtype == torch.bfloat16 \
                 and P % 8 == 0 and os.environ.get("MK_CONV_WGRAD", "hip") == "hip":
             # hand-written bf16 MFMA kernel: pixel slabs per workgroup, fp32 atomics into gW
-            from . import _lib, ops
-            gw32 = torch.zeros(O, I, dtype=torch.float32, device=x3.device)
-            _lib.check(_lib.load().mk_conv1x1_wgrad(gy.data_ptr(), x3.contiguous().data_ptr(), gw32.data_ptr(), B, O, I, P,
-                                                    ops._stream()), "mk_conv1x1_wgrad")
-            gw = gw32.to(w.dtype)
+            from . import ops
+            gw = ops.conv1x1_wgrad_raw(gy, x3.contiguous()).to(w.dtype)
         elif ctx.needs_input_grad[1]:
             S = _PointwiseConv.SPLIT
             while S > 1 and P % S:

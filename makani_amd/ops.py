@@ -280,6 +280,18 @@ def diag_contract(x, w):
     return _DiagContract.apply(x.contiguous(), w.contiguous())
 
 
+def conv1x1_wgrad_raw(gy, x3):
+    """gW[o][i] = sum_{b,p} gy[b][o][p] x3[b][i][p]: bf16 [B,O,P], [B,I,P] -> fp32 [O,I] (HIP bf16 MFMA kernel)."""
+    _need_cuda(gy, x3)
+    assert gy.is_contiguous() and x3.is_contiguous() and gy.dtype == torch.bfloat16 and x3.dtype == torch.bfloat16
+    b, o, p = gy.shape
+    i = x3.shape[1]
+    gw = torch.zeros(o, i, dtype=torch.float32, device=x3.device)
+    _lib.check(_lib.load().mk_conv1x1_wgrad(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, _stream()),
+               "mk_conv1x1_wgrad")
+    return gw
+
+
 def conv1x1_supported(x3, a):
     """bf16 [B, K, P] field and [M, K] matrix with 16-byte aligned rows."""
     return (x3.is_cuda and x3.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and x3.shape[1] % 8 == 0

@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 out=gpurun_out
 timeout -k 10 500 python3 bench.py > $out/${tag}_bench.json 2> $out/${tag}_bench.err || exit 1
 tail -1 $out/${tag}_bench.json | cut -c1-400
-rocprofv3 --kernel-trace --stats -d $out/${tag}_prof -o runc -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing > $out/${tag}_prof.log 2>&1 || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_prof -o runc -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-kernel-timing > $out/${tag}_prof.log 2>&1 || exit 2
 echo "kernel trace done"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c -d $out/${tag}_traffic/pmc_$c -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/${tag}_pmc_$c.log 2>&1 || exit 3
+  rocprofv3 --pmc $c --output-format csv -d $out/${tag}_traffic/pmc_$c -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/${tag}_pmc_$c.log 2>&1 || exit 3
   echo "pmc $c done"
 done
