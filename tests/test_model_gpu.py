@@ -63,6 +63,27 @@ def test_spectral_conv_vs_oracle(dev, grids, shapes):
     assert rel(yb.float(), yob.float()) < 1e-2
 
 
+def test_spectral_conv_production_size_vs_oracle(dev):
+    """BASELINE.json configs[1]: one spectral layer on 73 channels at 721x1440 (equiangular) -> 240x480
+    (legendre-gauss), 240 x 241 modes, forward + residual against the CPU oracle (tolerance 1e-5)."""
+    from makani_amd.sht import RealSHT, InverseRealSHT
+    from makani_amd.spectral_convolution import SpectralConv
+    from oracle import spectral as osp
+    torch.manual_seed(7)
+    L, M, C = 240, 241, 73
+    conv = SpectralConv(RealSHT(721, 1440, L, M, "equiangular"), InverseRealSHT(240, 480, L, M, "legendre-gauss"), C, C,
+                        operator_type="dhconv").to(dev)
+    ref = osp.SpectralConv(osp.TorchRealSHT(721, 1440, L, M, "equiangular"),
+                           osp.TorchInverseRealSHT(240, 480, L, M, "legendre-gauss"), C, C, operator_type="dhconv")
+    conv.load_state_dict(ref.state_dict())
+    x = torch.randn(1, C, 721, 1440)
+    with torch.no_grad():
+        y, r = conv(x.to(dev))
+        yo, ro = ref(x)
+    assert tuple(y.shape) == (1, C, 240, 480)
+    assert rel(y, yo) < TOL and rel(r, ro) < TOL
+
+
 def test_generic_path_with_foreign_transforms(dev):
     """Duck-typed transforms (RealFFT2 seam, layers.py:219-287) + get_contract_fun('dhconv') dense semantics."""
     import os
@@ -97,6 +118,25 @@ NET_CASES = [
     dict(inp_shape=(33, 64), out_shape=(33, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=8, num_layers=2),
     dict(inp_shape=(91, 180), out_shape=(91, 180), scale_factor=3, inp_chans=5, out_chans=5, embed_dim=16, num_layers=3),
 ]
+
+
+def test_sfno_full_config_forward_vs_oracle(dev):
+    """BASELINE.json configs[2]: sfno_linear_73chq_sc3_layers8_edim384 full forward, batch 1, fp32, against the CPU
+    oracle with identical (random-init) weights: 289 M parameters, 73 x 721 x 1440 in and out."""
+    import bench
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from oracle import spectral as osp
+    torch.manual_seed(333)
+    ref = osp.SphericalFourierNeuralOperatorNet(**bench.CONFIG)
+    net = SphericalFourierNeuralOperatorNet(**bench.CONFIG)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    net = net.to(dev)
+    x = torch.randn(1, 73, 721, 1440)
+    with torch.no_grad():
+        y = net(x.to(dev))
+        yo = ref(x)
+    assert tuple(y.shape) == (1, 73, 721, 1440)
+    assert rel(y, yo) < TOL
 
 
 @pytest.mark.parametrize("kw", NET_CASES)
