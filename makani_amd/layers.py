@@ -24,9 +24,13 @@ class _PointwiseConv(torch.autograd.Function):
     SPLIT = int(__import__("os").environ.get("MK_WGRAD_SPLIT", "32"))
 
     @staticmethod
-    def forward(ctx, x3, w, addend):
-        # x3 [B, I, P], w [O, I], optional addend [B, O, P] (skip connection folded into the GEMM
-        # epilogue: y = addend + W x); dtypes already equal (autocast handled by the caller)
+    def forward(ctx, x3, w_master, addend):
+        # x3 [B, I, P], w_master [O, I] (the parameter view, any float dtype), optional addend [B, O, P] (skip
+        # connection folded into the GEMM epilogue: y = addend + W x).  The weight is cast to the activation dtype
+        # here, inside the node, so its gradient goes back in fp32 straight from the wgrad kernel (no bf16 round
+        # trip, two tiny cast kernels fewer per convolution).
+        w = w_master if w_master.dtype == x3.dtype else w_master.to(x3.dtype)
+        ctx.master_dtype = w_master.dtype
         ctx.save_for_backward(x3, w)
         ctx.has_addend = addend is not None
         if addend is not None:
@@ -54,7 +58,7 @@ class _PointwiseConv(torch.autograd.Function):
                 and P % 8 == 0 and os.environ.get("MK_CONV_WGRAD", "hip") == "hip":
             # hand-written bf16 MFMA kernel: pixel slabs per workgroup, fp32 atomics into gW
             from . import ops
-            gw = ops.conv1x1_wgrad_raw(gy, x3.contiguous()).to(w.dtype)
+            gw = ops.conv1x1_wgrad_raw(gy, x3.contiguous()).to(ctx.master_dtype)
         elif ctx.needs_input_grad[1]:
             S = _PointwiseConv.SPLIT
             while S > 1 and P % S:
@@ -67,7 +71,7 @@ class _PointwiseConv(torch.autograd.Function):
                 b = x3[bi].view(I, S, kc).permute(1, 2, 0)
                 part = torch.bmm(a, b).float().sum(0)
                 gw32 = part if gw32 is None else gw32 + part
-            gw = gw32.to(w.dtype)
+            gw = gw32.to(ctx.master_dtype)
         return gx, gw, ga
 
 
@@ -87,11 +91,9 @@ class Conv1x1(nn.Conv2d):
         # NOTE: torch.matmul(2-D, 3-D) folds through a transposed *copy* of the activation; mm / bmm on
         # the [C, H*W] row-major view go straight to hipBLASLt with no copy in forward or backward
         if torch.is_autocast_enabled():
-            dt = torch.get_autocast_dtype('cuda')
-            x3, w = x.view(B, C, H * W).to(dt), w.to(dt)
+            x3 = x.view(B, C, H * W).to(torch.get_autocast_dtype('cuda'))
         else:
             x3 = x.view(B, C, H * W)
-            w = w.to(x3.dtype)
         with torch.autocast("cuda", enabled=False):
             a3 = None
             if addend is not None:
