@@ -177,6 +177,17 @@ int mk_instnorm_bwd(const void* x, const void* gy, const float* stats, const flo
                     void* gx, double* workspace, int dtype, int rows, int C, long long P, int fuse_gelu,
                     void* stream);
 
+/* Split-phase forms for rows sharded over ranks (DistributedInstanceNorm2d, makani/mpu/layer_norm.py:27-114):
+ * phase 1 = local row sums into `workspace` ([rows][2] doubles: sum x, sum x^2 / sum g', sum g' xhat);
+ * the caller all-reduces `workspace` over the ranks sharing the rows; phase 2 = apply with the reduced sums and
+ * `count` = the global number of elements per row.  phase 0 = both (count = P): the single-GPU calls above. */
+int mk_instnorm_fwd_ex(const void* x, const float* weight, const float* bias, void* y, float* stats,
+                       double* workspace, int dtype, int rows, int C, long long P, long long count, float eps,
+                       int fuse_gelu, int phase, void* stream);
+int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const float* weight, const float* bias,
+                       void* gx, double* workspace, int dtype, int rows, int C, long long P, long long count,
+                       int fuse_gelu, int phase, void* stream);
+
 /* ---- 1x1 convolution weight gradient (bf16 MFMA) ------------------------------------------ */
 /* gw[o][i] += sum over (b, p) of gy[b][o][p] * x[b][i][p]; gy, x bf16 [B][C][P] (P multiple of 8), gw fp32
  * [cout][cin] accumulated with atomics (caller zeroes it).  The weight gradient of nn.Conv2d(cin, cout, 1)

@@ -51,6 +51,10 @@ SIGNATURES = {
     "mk_bias_gelu_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_instnorm_fwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _c_float,
                                  _c_int, _vp]),
+    "mk_instnorm_fwd_ex": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong,
+                                    ctypes.c_longlong, _c_float, _c_int, _c_int, _vp]),
+    "mk_instnorm_bwd_ex": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong,
+                                    ctypes.c_longlong, _c_int, _c_int, _vp]),
     "mk_conv1x1_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_conv1x1_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_instnorm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong,

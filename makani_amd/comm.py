@@ -19,6 +19,7 @@ import torch.distributed as dist
 
 _LEAVES = ["h", "w", "fin", "fout"]
 _state = None  # dict: sizes, ranks, groups
+_lane = 0      # which copy of the group tree the collectives of the calling code use (see add_lane)
 
 
 def _require():
@@ -33,8 +34,59 @@ def get_rank(name):
     return _state["ranks"][name] if _require() else 0
 
 
-def get_group(name):
-    return _state["groups"].get(name) if _state is not None else None
+def get_group(name, lane=None):
+    if _state is None:
+        return None
+    lane = _lane if lane is None else lane
+    if lane == 0:
+        return _state["groups"].get(name)
+    return _state["lanes"][lane - 1].get(name)
+
+
+# -- lanes: independent copies of the group tree (separate RCCL communicators, hence separate collective queues).
+# Two micro-batches running on two HIP streams use one lane each, so the all-to-alls of one overlap the kernels of
+# the other instead of queueing behind the other micro-batch's collectives (bench.py, N > 1).
+def add_lane():
+    """Create one more copy of every process group (collective: every rank calls it, in the same order)."""
+    if _state is None:
+        return 0
+    groups = {}
+    for gname, buckets in _state["members"].items():
+        for rl in buckets:
+            grp = dist.new_group(rl) if len(rl) > 1 else None
+            if _state["world_rank"] in rl:
+                groups[gname] = grp
+    _state["lanes"].append(groups)
+    return len(_state["lanes"])
+
+
+def num_lanes():
+    return 1 + (len(_state["lanes"]) if _state is not None else 0)
+
+
+def get_lane():
+    return _lane
+
+
+def set_lane(i):
+    global _lane
+    if i < 0 or i >= num_lanes():
+        raise ValueError(f"lane {i} does not exist ({num_lanes()} lane(s))")
+    _lane = int(i)
+
+
+class lane:
+    """``with comm.lane(i):`` -- collectives issued inside use lane i (autograd nodes re-enter their forward lane)."""
+
+    def __init__(self, i):
+        self.i, self.prev = i, 0
+
+    def __enter__(self):
+        self.prev = get_lane()
+        set_lane(self.i)
+
+    def __exit__(self, *exc):
+        set_lane(self.prev)
 
 
 def get_root(name):
@@ -109,13 +161,14 @@ def init(model_parallel_sizes=(1, 1, 1, 1), model_parallel_names=("h", "w", "fin
     members = {"h": ["h"], "w": ["w"], "fin": ["fin"], "fout": ["fout"], "data": ["data"],
                "spatial": ["h", "w"], "matmul": ["fin", "fout"], "model": ["h", "w", "fin", "fout"]}
     all_coords = [_coords(r, sizes) for r in range(world_size)]
-    groups, ranks, roots = {}, {}, {}
+    groups, ranks, roots, member_lists = {}, {}, {}, {}
     for gname, axes in members.items():
         # ranks sharing every coordinate NOT in `axes` form one group; every rank creates all of them
         buckets = {}
         for r, c in enumerate(all_coords):
             key = tuple(c[a] for a in ["h", "w", "fin", "fout", "data"] if a not in axes)
             buckets.setdefault(key, []).append(r)
+        member_lists[gname] = [buckets[key] for key in sorted(buckets)]
         for key in sorted(buckets):
             rl = buckets[key]
             grp = dist.new_group(rl) if len(rl) > 1 else None
@@ -123,15 +176,18 @@ def init(model_parallel_sizes=(1, 1, 1, 1), model_parallel_names=("h", "w", "fin
                 groups[gname] = grp
                 ranks[gname] = rl.index(rank)
                 roots[gname] = min(rl)
+    global _lane
+    _lane = 0
     _state = {"sizes": sizes, "ranks": ranks, "groups": groups, "roots": roots, "world_size": world_size,
-              "world_rank": rank, "local_rank": local_rank}
+              "world_rank": rank, "local_rank": local_rank, "members": member_lists, "lanes": []}
     if verbose and rank == 0:
         print(f"makani_amd.comm: world {world_size}, sizes {sizes}")
     return model_size
 
 
 def cleanup():
-    global _state
+    global _state, _lane
     _state = None
+    _lane = 0
     if dist.is_initialized():
         dist.destroy_process_group()

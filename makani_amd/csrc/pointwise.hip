@@ -172,10 +172,11 @@ template <typename T, bool GELU>
 __global__ __launch_bounds__(kT) void instnorm_apply_kernel(const T* __restrict__ x, const double* __restrict__ sums,
                                                             const float* __restrict__ w, const float* __restrict__ b,
                                                             T* __restrict__ y, float* __restrict__ stats, int C,
-                                                            long long P, float eps) {
+                                                            long long P, double count, float eps) {
+    // count = number of elements the sums run over: P, or the global H*W when the sums were reduced over ranks
     const int row = blockIdx.y, c = row % C;
-    const double mean_d = sums[2 * row] / (double)P;
-    double var_d = sums[2 * row + 1] / (double)P - mean_d * mean_d;
+    const double mean_d = sums[2 * row] / count;
+    double var_d = sums[2 * row + 1] / count - mean_d * mean_d;
     if (var_d < 0.0) var_d = 0.0;
     const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)eps));
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -250,11 +251,11 @@ __global__ __launch_bounds__(kT) void instnorm_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ w, const float* __restrict__ b,
                                                                 const double* __restrict__ sums, T* __restrict__ gx, int C,
-                                                                long long P) {
+                                                                long long P, double count) {
     const int row = blockIdx.y, c = row % C;
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     const float wc = w ? w[c] : 1.f, bc = b ? b[c] : 0.f;
-    const float m1 = (float)(sums[2 * row] / (double)P), m2 = (float)(sums[2 * row + 1] / (double)P);
+    const float m1 = (float)(sums[2 * row] / count), m2 = (float)(sums[2 * row + 1] / count);
     const float k = wc * rstd;
     const long long ro = (long long)row * P;
     for_chunk<T>(P, [&](long long off, int n) {
@@ -320,26 +321,69 @@ extern "C" int mk_bias_gelu_bwd(const void* x, const float* bias, const void* gy
     return 0;
 }
 
+// phase 0: sums + apply (single GPU).  phase 1: local row sums only (into workspace).  phase 2: apply only --
+// workspace holds the sums reduced over the ranks that share the rows, count their total element count.
+extern "C" int mk_instnorm_fwd_ex(const void* x, const float* weight, const float* bias, void* y, float* stats,
+                                  double* workspace, int dtype, int rows, int C, long long P, long long count, float eps,
+                                  int fuse_gelu, int phase, void* stream) {
+    MK_REQUIRE(x && workspace, "null pointer");
+    MK_REQUIRE(phase == 1 || (y && stats), "null pointer");
+    MK_REQUIRE(phase >= 0 && phase <= 2 && count > 0, "bad phase / count");
+    PW_CHECK();
+    hipStream_t st = (hipStream_t)stream;
+    if (phase != 2) (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * rows, st);
+    const dim3 g = pw_grid(rows, P);
+    const double cnt = (double)count;
+#define LAUNCH(T)                                                                                              \
+    if (phase != 2) hipLaunchKernelGGL(rowsum2_kernel<T>, g, dim3(kT), 0, st, (const T*)x, workspace, P);      \
+    if (phase != 1) {                                                                                          \
+        if (fuse_gelu)                                                                                         \
+            hipLaunchKernelGGL((instnorm_apply_kernel<T, true>), g, dim3(kT), 0, st, (const T*)x, workspace, weight, \
+                               bias, (T*)y, stats, C, P, cnt, eps);                                            \
+        else                                                                                                   \
+            hipLaunchKernelGGL((instnorm_apply_kernel<T, false>), g, dim3(kT), 0, st, (const T*)x, workspace, weight, \
+                               bias, (T*)y, stats, C, P, cnt, eps);                                            \
+    }
+    if (dtype == 0) {
+        LAUNCH(float)
+    } else {
+        LAUNCH(__hip_bfloat16)
+    }
+#undef LAUNCH
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int mk_instnorm_fwd(const void* x, const float* weight, const float* bias, void* y, float* stats,
                                double* workspace, int dtype, int rows, int C, long long P, float eps, int fuse_gelu,
                                void* stream) {
-    MK_REQUIRE(x && y && stats && workspace, "null pointer");
+    return mk_instnorm_fwd_ex(x, weight, bias, y, stats, workspace, dtype, rows, C, P, P, eps, fuse_gelu, 0, stream);
+}
+
+// phases as in mk_instnorm_fwd_ex; the phase-1 sums (sum g', sum g' xhat per row) are also the LOCAL bias / weight
+// gradient contributions
+extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const float* weight,
+                                  const float* bias, void* gx, double* workspace, int dtype, int rows, int C, long long P,
+                                  long long count, int fuse_gelu, int phase, void* stream) {
+    MK_REQUIRE(x && gy && stats && workspace, "null pointer");
+    MK_REQUIRE(phase == 1 || gx, "null pointer");
+    MK_REQUIRE(phase >= 0 && phase <= 2 && count > 0, "bad phase / count");
     PW_CHECK();
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * rows, st);
+    if (phase != 2) (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * rows, st);
     const dim3 g = pw_grid(rows, P);
-#define LAUNCH(T)                                                                                              \
-    hipLaunchKernelGGL(rowsum2_kernel<T>, g, dim3(kT), 0, st, (const T*)x, workspace, P);                      \
-    if (fuse_gelu)                                                                                             \
-        hipLaunchKernelGGL((instnorm_apply_kernel<T, true>), g, dim3(kT), 0, st, (const T*)x, workspace, weight, \
-                           bias, (T*)y, stats, C, P, eps);                                                     \
-    else                                                                                                       \
-        hipLaunchKernelGGL((instnorm_apply_kernel<T, false>), g, dim3(kT), 0, st, (const T*)x, workspace, weight, \
-                           bias, (T*)y, stats, C, P, eps)
+    const double cnt = (double)count;
+#define LAUNCH(T, G)                                                                                               \
+    if (phase != 2)                                                                                                \
+        hipLaunchKernelGGL((instnorm_bwd_sums_kernel<T, G>), g, dim3(kT), 0, st, (const T*)x, (const T*)gy, stats, weight, \
+                           bias, workspace, C, P);                                                                 \
+    if (phase != 1)                                                                                                \
+        hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, G>), g, dim3(kT), 0, st, (const T*)x, (const T*)gy, stats, weight, \
+                           bias, workspace, (T*)gx, C, P, cnt);
     if (dtype == 0) {
-        LAUNCH(float);
+        if (fuse_gelu) { LAUNCH(float, true) } else { LAUNCH(float, false) }
     } else {
-        LAUNCH(__hip_bfloat16);
+        if (fuse_gelu) { LAUNCH(__hip_bfloat16, true) } else { LAUNCH(__hip_bfloat16, false) }
     }
 #undef LAUNCH
     MK_LAUNCH_CHECK();
@@ -349,22 +393,5 @@ extern "C" int mk_instnorm_fwd(const void* x, const float* weight, const float* 
 extern "C" int mk_instnorm_bwd(const void* x, const void* gy, const float* stats, const float* weight,
                                const float* bias, void* gx, double* workspace, int dtype, int rows, int C, long long P,
                                int fuse_gelu, void* stream) {
-    MK_REQUIRE(x && gy && gx && stats && workspace, "null pointer");
-    PW_CHECK();
-    hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * rows, st);
-    const dim3 g = pw_grid(rows, P);
-#define LAUNCH(T, G)                                                                                               \
-    hipLaunchKernelGGL((instnorm_bwd_sums_kernel<T, G>), g, dim3(kT), 0, st, (const T*)x, (const T*)gy, stats, weight, \
-                       bias, workspace, C, P);                                                                     \
-    hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, G>), g, dim3(kT), 0, st, (const T*)x, (const T*)gy, stats, weight, \
-                       bias, workspace, (T*)gx, C, P)
-    if (dtype == 0) {
-        if (fuse_gelu) { LAUNCH(float, true); } else { LAUNCH(float, false); }
-    } else {
-        if (fuse_gelu) { LAUNCH(__hip_bfloat16, true); } else { LAUNCH(__hip_bfloat16, false); }
-    }
-#undef LAUNCH
-    MK_LAUNCH_CHECK();
-    return 0;
+    return mk_instnorm_bwd_ex(x, gy, stats, weight, bias, gx, workspace, dtype, rows, C, P, P, fuse_gelu, 0, stream);
 }

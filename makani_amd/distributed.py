@@ -80,13 +80,12 @@ class _DistributedTranspose(torch.autograd.Function):
     def forward(ctx, x, dims, dim1_split_sizes, group_name):
         group = comm.get_group(group_name)
         out, dim0_split_sizes = _transpose(x, dims[0], dims[1], dim1_split_sizes, group)
-        ctx.dims, ctx.dim0_split_sizes, ctx.group_name = dims, dim0_split_sizes, group_name
+        ctx.dims, ctx.dim0_split_sizes, ctx.group = dims, dim0_split_sizes, group   # backward stays on the forward's lane
         return out
 
     @staticmethod
     def backward(ctx, go):
-        group = comm.get_group(ctx.group_name)
-        gi, _ = _transpose(go.contiguous(), ctx.dims[1], ctx.dims[0], ctx.dim0_split_sizes, group)
+        gi, _ = _transpose(go.contiguous(), ctx.dims[1], ctx.dims[0], ctx.dim0_split_sizes, ctx.group)
         return gi, None, None, None
 
 

@@ -4,11 +4,15 @@ Mirrors ``makani/mpu/layer_norm.py:27-114`` (``DistributedInstanceNorm2d``): loc
 (var, mean, count) per (b, c), merged across the ``spatial`` group with Welford's
 update, then normalise + affine.  Differences, both documented in DESIGN.md:
 
+* on the GPU the norm runs on the HIP instance-norm kernels in two phases (local row sums -> one all-reduce of
+  ``[B*C, 2]`` float64 sums -> apply, optionally with the block's GELU fused), the torch-op formulation below is
+  the CPU / unsupported-shape path (12 ms vs 1.2 ms per full-resolution norm, fwd+bwd, on one N = 8 shard);
 * the three per-rank statistics travel in ONE all-gather (``[B, C, 3]``) instead of three;
 * statistics keep their batch dimension (``[B, C, 1, 1]``); the reference reshapes to
   ``(1, -1, 1, 1)`` (layer_norm.py:85-86), which is only valid for local batch 1.
 """
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import comm
@@ -20,6 +24,7 @@ class DistributedInstanceNorm2d(nn.Module):
         super().__init__()
         self.eps = eps
         self.affine = affine
+        self._counts = {}
         if self.affine:
             self.weight = nn.Parameter(torch.ones(num_features))
             self.bias = nn.Parameter(torch.zeros(num_features))
@@ -45,7 +50,26 @@ class DistributedInstanceNorm2d(nn.Module):
         var = m2 / count
         return var.unsqueeze(-1).unsqueeze(-1), mean.unsqueeze(-1).unsqueeze(-1)
 
-    def forward(self, x):
+    def _global_count(self, x):
+        """H*W summed over the spatial group (shards are uneven): one tiny all-reduce per local shape, cached."""
+        key = (x.shape[-2], x.shape[-1])
+        if key not in self._counts:
+            t = torch.tensor([float(key[0] * key[1])], dtype=torch.float64, device=x.device)
+            dist.all_reduce(t, group=comm.get_group("spatial"))
+            self._counts[key] = int(round(t.item()))
+        return self._counts[key]
+
+    def forward(self, x, fuse_gelu=False):
+        from . import ops
+        if x.is_cuda and x.dim() == 4 and ops.pointwise_supported(x) and comm.get_size("spatial") > 1:
+            # HIP path: local row sums -> one all-reduce of [B*C, 2] doubles -> apply (+ fused GELU); same two
+            # streaming passes as the single-GPU norm instead of ~10 elementwise torch passes in fp32
+            return ops.instance_norm(x.contiguous(), self.weight if self.affine else None, self.bias if self.affine else None,
+                                     self.eps, fuse_gelu, comm.get_group("spatial"), self._global_count(x))
+        y = self._forward_torch(x)
+        return torch.nn.functional.gelu(y) if fuse_gelu else y
+
+    def _forward_torch(self, x):
         with torch.autocast(device_type=x.device.type, enabled=False):
             dtype = x.dtype
             xf = x.float()

@@ -17,14 +17,14 @@ from . import comm
 class _CopyToParallelRegion(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, name):
-        ctx.name = name
+        ctx.name, ctx.lane = name, comm.get_lane()
         return x
 
     @staticmethod
     def backward(ctx, g):
         if comm.get_size(ctx.name) > 1:
             g = g.contiguous().clone()
-            dist.all_reduce(g, group=comm.get_group(ctx.name))
+            dist.all_reduce(g, group=comm.get_group(ctx.name, ctx.lane))
         return g, None
 
 
@@ -75,13 +75,14 @@ class _ScatterToParallelRegion(torch.autograd.Function):
     def forward(ctx, x, dim, name):
         from .distributed import compute_split_shapes
         size, rank = comm.get_size(name), comm.get_rank(name)
-        ctx.dim, ctx.name = dim, name
+        ctx.dim, ctx.name, ctx.lane = dim, name, comm.get_lane()
         ctx.shapes = compute_split_shapes(x.shape[dim], size)
         return torch.split(x, ctx.shapes, dim=dim)[rank].contiguous()
 
     @staticmethod
     def backward(ctx, g):
-        return _GatherFromParallelRegion.apply(g, ctx.dim, ctx.shapes, ctx.name), None, None
+        with comm.lane(ctx.lane):
+            return _GatherFromParallelRegion.apply(g, ctx.dim, ctx.shapes, ctx.name), None, None
 
 
 def copy_to_parallel_region(x, name):

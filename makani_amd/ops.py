@@ -500,10 +500,15 @@ class _BiasGelu(torch.autograd.Function):
 
 
 class _InstanceNorm(torch.autograd.Function):
-    """Affine instance norm over (H, W) with optional fused GELU; statistics in fp32/fp64."""
+    """Affine instance norm over (H, W) with optional fused GELU; statistics in fp32/fp64.
+
+    ``group`` / ``count``: the rows are sharded over the ranks of ``group`` (spatial model parallelism) -- the local
+    row sums are all-reduced between the two kernel phases and ``count`` is the global number of elements per row.
+    The weight / bias gradients returned are the LOCAL contributions (shared-weight reduction sums them later).
+    """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, fuse_gelu):
+    def forward(ctx, x, weight, bias, eps, fuse_gelu, group, count):
         _need_cuda(x)
         B, C, H, W = x.shape
         y = torch.empty_like(x)
@@ -511,37 +516,58 @@ class _InstanceNorm(torch.autograd.Function):
         bf = None if bias is None else bias.detach().float().contiguous()
         stats = torch.empty(B * C, 2, dtype=torch.float32, device=x.device)
         ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
-        _lib.check(_lib.load().mk_instnorm_fwd(x.data_ptr(), 0 if wf is None else wf.data_ptr(),
-                                               0 if bf is None else bf.data_ptr(), y.data_ptr(), stats.data_ptr(),
-                                               ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, float(eps), int(fuse_gelu),
-                                               _stream()), "mk_instnorm_fwd")
+        lib = _lib.load()
+        cnt = H * W if group is None else int(count)
+
+        def run(phase):
+            _lib.check(lib.mk_instnorm_fwd_ex(x.data_ptr(), 0 if wf is None else wf.data_ptr(),
+                                              0 if bf is None else bf.data_ptr(), y.data_ptr(), stats.data_ptr(),
+                                              ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, cnt, float(eps),
+                                              int(fuse_gelu), phase, _stream()), "mk_instnorm_fwd_ex")
+        if group is None:
+            run(0)
+        else:
+            run(1)
+            torch.distributed.all_reduce(ws, group=group)
+            run(2)
         empty = x.new_empty(0, dtype=torch.float32)
         ctx.save_for_backward(x, stats, wf if wf is not None else empty, bf if bf is not None else empty)
         ctx.cfg = (weight is not None, bias is not None, bool(fuse_gelu),
-                   None if weight is None else weight.dtype, None if bias is None else bias.dtype)
+                   None if weight is None else weight.dtype, None if bias is None else bias.dtype, group, cnt)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, stats, wf, bf = ctx.saved_tensors
-        has_w, has_b, fuse, wdt, bdt = ctx.cfg
+        has_w, has_b, fuse, wdt, bdt, group, cnt = ctx.cfg
         B, C, H, W = x.shape
         gy = gy.contiguous()
         gx = torch.empty_like(x)
         ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
-        _lib.check(_lib.load().mk_instnorm_bwd(x.data_ptr(), gy.data_ptr(), stats.data_ptr(),
-                                               wf.data_ptr() if has_w else 0, bf.data_ptr() if has_b else 0,
-                                               gx.data_ptr(), ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, int(fuse),
-                                               _stream()), "mk_instnorm_bwd")
-        sums = ws.view(B, C, 2).sum(0)
+        lib = _lib.load()
+
+        def run(phase):
+            _lib.check(lib.mk_instnorm_bwd_ex(x.data_ptr(), gy.data_ptr(), stats.data_ptr(),
+                                              wf.data_ptr() if has_w else 0, bf.data_ptr() if has_b else 0,
+                                              gx.data_ptr(), ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, cnt, int(fuse),
+                                              phase, _stream()), "mk_instnorm_bwd_ex")
+        if group is None:
+            run(0)
+            local = ws
+        else:
+            run(1)
+            local = ws.clone()
+            torch.distributed.all_reduce(ws, group=group)
+            run(2)
+        sums = local.view(B, C, 2).sum(0)
         gw = sums[:, 1].to(wdt) if has_w else None
         gb = sums[:, 0].to(bdt) if has_b else None
-        return gx, gw, gb, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def bias_gelu(x, bias):
     return _BiasGelu.apply(x, bias)
 
 
-def instance_norm(x, weight, bias, eps=1e-5, fuse_gelu=False):
-    return _InstanceNorm.apply(x, weight, bias, eps, fuse_gelu)
+def instance_norm(x, weight, bias, eps=1e-5, fuse_gelu=False, group=None, count=None):
+    return _InstanceNorm.apply(x, weight, bias, eps, fuse_gelu, group, count)

@@ -114,7 +114,7 @@ class FourierNeuralOperatorBlock(nn.Module):
 
     def forward(self, x):
         x, residual = self.filter(x)
-        if (isinstance(self.norm0, InstanceNorm2d) and not hasattr(self, "inner_skip")
+        if (isinstance(self.norm0, (InstanceNorm2d, DistributedInstanceNorm2d)) and not hasattr(self, "inner_skip")
                 and hasattr(self, "act_layer0") and _is_exact_gelu(self.act_layer0)):
             x = self.norm0(x, fuse_gelu=True)      # norm0 + GELU in one apply pass
         else:

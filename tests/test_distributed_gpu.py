@@ -80,6 +80,39 @@ def _body_sht(dev):
     assert _rel(_gather(yl, 2, "h"), yo) < 1e-5
 
 
+def _body_norm(dev):
+    """DistributedInstanceNorm2d on the HIP kernels (local sums -> all-reduce -> apply) vs the serial torch norm,
+    uneven latitude shards, with and without the fused GELU, including the shared weight / bias gradients."""
+    from makani_amd import mappings
+    from makani_amd.layer_norm import DistributedInstanceNorm2d
+    torch.manual_seed(5)
+    B, C, H, W = 2, 6, 33, 64
+    xg, gg = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    wg, bg = torch.rand(C) + 0.5, torch.randn(C)
+    for fuse in (False, True):
+        ref = torch.nn.InstanceNorm2d(C, eps=1e-6, affine=True)
+        with torch.no_grad():
+            ref.weight.copy_(wg)
+            ref.bias.copy_(bg)
+        xo = xg.clone().requires_grad_(True)
+        yo = ref(xo)
+        if fuse:
+            yo = torch.nn.functional.gelu(yo)
+        yo.backward(gg)
+        mod = DistributedInstanceNorm2d(C, eps=1e-6, affine=True).to(dev)
+        with torch.no_grad():
+            mod.weight.copy_(wg)
+            mod.bias.copy_(bg)
+        xl = _shard(xg, 2, "h").to(dev).requires_grad_(True)
+        yl = mod(xl, fuse_gelu=fuse)
+        yl.backward(_shard(gg, 2, "h").to(dev))
+        mappings.reduce_shared_gradients(mod)
+        assert _rel(_gather(yl.detach(), 2, "h"), yo.detach()) < 1e-5
+        assert _rel(_gather(xl.grad, 2, "h"), xo.grad) < 1e-5
+        assert _rel(mod.weight.grad, ref.weight.grad) < 1e-5
+        assert _rel(mod.bias.grad, ref.bias.grad) < 1e-5
+
+
 def _body_net(dev):
     from makani_amd import comm, mappings
     from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
@@ -136,7 +169,7 @@ def _worker(rank, world, port, what, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("what", ["sht", "net"])
+@pytest.mark.parametrize("what", ["sht", "norm", "net"])
 def test_h2_on_one_gpu(what):
     assert torch.cuda.device_count() >= 1
     ctx = mp.get_context("spawn")
