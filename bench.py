@@ -292,8 +292,30 @@ def main():
     if not args.no_kernel_timing:
         timer.install()
 
+    # N > 1: two micro-batches on two HIP streams / RCCL communicators, so the distributed-SHT all-to-alls of one
+    # overlap the kernels of the other (makani_amd/pipeline.py).  MK_BENCH_MICROBATCH=1 restores the single stream.
+    nmb = int(os.environ.get("MK_BENCH_MICROBATCH", "2" if (world > 1 and B % 2 == 0 and not args.graph) else "1"))
+    runner = None
+    if nmb > 1:
+        from makani_amd.pipeline import MicroBatchRunner
+        assert B % nmb == 0, "the local batch must divide into the micro-batches"
+        runner = MicroBatchRunner(nmb)
+        mb = B // nmb
+
+        def mb_loss(j):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                pred = net(inp[j * mb:(j + 1) * mb])
+            return (((pred.float() - tar[j * mb:(j + 1) * mb]) ** 2) * wq).sum() / (B * 73)
+
     def step():
         opt.zero_grad(set_to_none=True)
+        if runner is not None:
+            loss = runner.forward(mb_loss)
+            loss.backward()
+            runner.sync()
+            mappings.reduce_shared_gradients(net)
+            opt.step()
+            return loss
         with torch.autocast("cuda", dtype=torch.bfloat16):
             pred = net(inp)
         loss = (((pred.float() - tar) ** 2) * wq).sum() / (B * 73)
@@ -387,7 +409,8 @@ def main():
             "config": {"workload": "sfno_linear_73chq_sc3_layers8_edim384 fwd+bwd+Adam, 73ch 721x1440, per-GPU batch 1",
                        "global_batch": B, "parallelism": f"h{hsize}", "spectral_dtype": "f32 (GEMMs as 6 bf16 MFMA products of exact 3-way operand splits)"
                        if spectral_mode == "bf16x3" else "f32",
-                       "step_launch": "hipGraph replay" if args.graph else "eager"},
+                       "step_launch": "hipGraph replay" if args.graph else "eager",
+                       "micro_batches": nmb},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
             "kernel_timing": ("HIP events: all kernels over the last %d warm-up step(s), the roofline kernel over the timed region"
                               % n_probe) if n_probe else ("HIP events over an eager pre-pass" if args.graph else

@@ -150,6 +150,52 @@ def _body_net(dev):
         assert _rel(got, want, floor=0.1 * scale) < 1e-4, n
 
 
+def _body_pipeline(dev):
+    """The SFNO step as two overlapped micro-batches (two streams, two comm lanes) on h = 2 vs the serial oracle."""
+    from makani_amd import comm, mappings
+    from makani_amd.pipeline import MicroBatchRunner
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from makani_amd.distributed import compute_split_shapes
+    from oracle import spectral as osp
+    torch.manual_seed(333)
+    kw = dict(inp_shape=(64, 128), out_shape=(64, 128), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=8, num_layers=2)
+    ref = osp.SphericalFourierNeuralOperatorNet(**kw)
+    net = SphericalFourierNeuralOperatorNet(**kw)
+    hs, hr = comm.get_size("h"), comm.get_rank("h")
+    sd = ref.state_dict()
+    for k in list(sd):
+        if k.endswith("filter.filter.weight"):
+            sd[k] = torch.split(sd[k], compute_split_shapes(sd[k].shape[-1], hs), dim=-1)[hr].contiguous()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    B = 2
+    xg, tg = torch.randn(B, 4, 64, 128), torch.randn(B, 3, 64, 128)
+    yo = ref(xg)
+    ((yo - tg) ** 2).sum().backward()
+    xl, tl = _shard(xg, 2, "h").to(dev), _shard(tg, 2, "h").to(dev)
+    runner = MicroBatchRunner(2)
+    assert comm.num_lanes() == 2
+    preds = [None, None]
+
+    def mb_loss(j):
+        preds[j] = net(xl[j:j + 1])
+        return ((preds[j] - tl[j:j + 1]) ** 2).sum()
+
+    runner.forward(mb_loss).backward()
+    runner.sync()
+    mappings.reduce_shared_gradients(net)
+    yl = torch.cat([p.detach() for p in preds], dim=0)
+    assert _rel(_gather(yl, 2, "h"), yo.detach()) < 2e-5
+    po = dict(ref.named_parameters())
+    scale = float(np.median([p.grad.norm().item() for p in po.values()]))
+    for n, p in net.named_parameters():
+        want = po[n].grad
+        if n.endswith("filter.filter.weight"):
+            want = torch.split(want, compute_split_shapes(want.shape[-1], hs), dim=-1)[hr]
+        got = p.grad if p.grad is not None else torch.zeros_like(p)
+        assert _rel(got, want, floor=0.1 * scale) < 1e-4, n
+
+
 def _worker(rank, world, port, what, q):
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -169,7 +215,7 @@ def _worker(rank, world, port, what, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("what", ["sht", "norm", "net"])
+@pytest.mark.parametrize("what", ["sht", "norm", "net", "pipeline"])
 def test_h2_on_one_gpu(what):
     assert torch.cuda.device_count() >= 1
     ctx = mp.get_context("spawn")
