@@ -52,12 +52,15 @@ def _transpose(x, dim0, dim1, dim1_split_sizes, group):
     dim0_split_sizes = compute_split_shapes(x.shape[dim0], size)
     chunks = torch.split(x, dim0_split_sizes, dim=dim0)
     in_splits = [c.numel() for c in chunks]
-    # pack: ONE strided copy per peer straight into the contiguous send buffer
-    send = torch.empty(sum(in_splits), dtype=x.dtype, device=x.device)
-    off = 0
-    for c, n in zip(chunks, in_splits):
-        send[off:off + n].view(c.shape).copy_(c)
-        off += n
+    if dim0 == 0 and x.is_contiguous():
+        send = x.view(-1)        # splitting the outermost axis: the peers' chunks already lie back to back
+    else:
+        # pack: ONE strided copy per peer straight into the contiguous send buffer
+        send = torch.empty(sum(in_splits), dtype=x.dtype, device=x.device)
+        off = 0
+        for c, n in zip(chunks, in_splits):
+            send[off:off + n].view(c.shape).copy_(c)
+            off += n
     shp = list(chunks[rank].shape)
     out_shapes = []
     for s in dim1_split_sizes:
@@ -71,6 +74,10 @@ def _transpose(x, dim0, dim1, dim1_split_sizes, group):
                                [2 * s for s in out_splits], [2 * s for s in in_splits], group=group)
     else:
         dist.all_to_all_single(recv, send, out_splits, in_splits, group=group)
+    if dim1 == 0:                # gathering the outermost axis: the received chunks ARE the result
+        o = list(shp)
+        o[0] = sum(dim1_split_sizes)
+        return recv.view(o), dim0_split_sizes
     parts = [p.view(o) for p, o in zip(torch.split(recv, out_splits), out_shapes)]
     return torch.cat(parts, dim=dim1), dim0_split_sizes
 
