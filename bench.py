@@ -77,11 +77,11 @@ class KernelTimer:
             return inner
 
         # algorithmic work per launch: only l >= m counted
-        def leg_fwd_work(out, xf, table, lmax, m_off=0):
-            mloc, k, bc = xf.shape
+        def leg_fwd_work(out, xf, table, lmax, m_off=0, mode=None, kmajor=False):
+            mloc, k, bc = (xf.shape[1], xf.shape[0], xf.shape[2]) if kmajor else xf.shape
             return 4.0 * tri_pairs(lmax, mloc, 0, m_off) * k * bc, "flop"
 
-        def leg_inv_work(out, c, table, nlat, m_off=0):
+        def leg_inv_work(out, c, table, nlat, m_off=0, mode=None, kmajor=False):
             lmax, mloc, bc = c.shape
             return 4.0 * tri_pairs(lmax, mloc, 0, m_off) * nlat * bc, "flop"
 
@@ -97,12 +97,13 @@ class KernelTimer:
             b, o, p = gy.shape
             return 2.0 * o * x3.shape[1] * p * b, "flop_bf16"
 
-        def rfft_work(out, x, tw, mmax, *s):
+        def rfft_work(out, x, tw, mmax, *s, **kw):
             bc, k, n = x.shape
             return float(k * bc * (x.element_size() * n + 8 * mmax)), "byte"
 
-        def irfft_work(out, xf, tw, nlon, *s):
-            m, k, bc = xf.shape
+        def irfft_work(out, xf, tw, nlon, *s, **kw):
+            kmajor = kw.get("kmajor", s[4] if len(s) > 4 else False)
+            m, k, bc = (xf.shape[1], xf.shape[0], xf.shape[2]) if kmajor else xf.shape
             return float(k * bc * (out.element_size() * nlon + 8 * m)), "byte"
 
         def layout_work(out, t, *a):

@@ -115,6 +115,20 @@ int mk_legendre_fwd_x3(const float* xf, const void* tab_x3, float* c,
 int mk_legendre_inv_x3(const float* c, const void* tab_x3, float* xf,
                        int bc, int nlat, int lmax, int mmax_loc, int m_off, int mmax_glob, void* stream);
 
+/* ---- latitude-major Fourier rows (distributed SHT) ---------------------------------------
+ * `_ex` forms with xf_layout: 0 = xf[m][k][bc] (all calls above), 1 = xf[k][m][bc].  With latitude
+ * outermost the two latitude all-to-alls of the distributed transform (makani/mpu/layers.py:38-169 pattern,
+ * torch_harmonics distributed_transpose_polar) gather / split the OUTERMOST axis, so the received chunks are the
+ * operand and the sent chunks lie back to back: no pack / concatenate copies on that side. */
+int mk_rfft_ex(const void* x, int x_dtype, float* xf, const float* twiddles, int bc, int nlat, int nlon,
+               int mmax, float scale0, float scale_m, float scale_h, int xf_layout, void* stream);
+int mk_irfft_ex(const float* xf, void* x, int x_dtype, const float* twiddles, int bc, int nlat, int nlon,
+                int mmax, float scale0, float scale_m, float scale_h, int xf_layout, void* stream);
+int mk_legendre_fwd_x3_ex(const float* xf, const void* tab_x3, float* c, int bc, int nlat, int lmax,
+                          int mmax_loc, int m_off, int mmax_glob, int xf_layout, void* stream);
+int mk_legendre_inv_x3_ex(const float* c, const void* tab_x3, float* xf, int bc, int nlat, int lmax,
+                          int mmax_loc, int m_off, int mmax_glob, int xf_layout, void* stream);
+
 /* ---- spectral filter contraction (K5) ---------------------------------- */
 /* y[l][m][b][o] = sum_i x[l][m][b][i] * w[l][i][o]  (complex), for global m <= l.
  * Replaces _contract_dhconv `einsum("bixy,iox->boxy")` (contractions.py:130-136,

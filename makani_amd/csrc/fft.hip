@@ -20,6 +20,14 @@
 
 namespace {
 
+// Layout of the Fourier rows xf: element (m, k, bc) at ((m * sm + k * sk) * BC + bc) complex numbers.
+//   [M][K][BC] (default): sm = K, sk = 1.     [K][M][BC] (latitude major, distributed SHT): sm = 1, sk = M.
+struct XfLayout {
+    int sm, sk;
+};
+static thread_local XfLayout g_xl = {0, 0};   // set by the C entry points before they launch
+
+
 // ---------------------------------------------------------------------------
 // compile-time helpers
 // ---------------------------------------------------------------------------
@@ -271,7 +279,7 @@ __device__ __forceinline__ float2 load_pair(const __hip_bfloat16* p) {
 template <int H, int G, typename TIn>
 __global__ __launch_bounds__(kThreads) void rfft_kernel(const TIn* __restrict__ x, float2* __restrict__ xf,
                                                         const float2* __restrict__ tw, int BC, int K, int M,
-                                                        float scale0, float scale_m, float scale_h) {
+                                                        float scale0, float scale_m, float scale_h, XfLayout xl) {
     constexpr int N = 2 * H, HP = H + 1;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -303,7 +311,7 @@ __global__ __launch_bounds__(kThreads) void rfft_kernel(const TIn* __restrict__ 
         const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y - b.y));
         const float2 o = mul_mi(cmul(tw2[m], d));
         const float s = (m == 0) ? scale0 : ((m == H) ? scale_h : scale_m);
-        xf[((size_t)m * K + k) * BC + bc] = make_float2(s * (e.x + o.x), s * (e.y + o.y));
+        xf[((size_t)m * xl.sm + (size_t)k * xl.sk) * BC + bc] = make_float2(s * (e.x + o.x), s * (e.y + o.y));
     }
 }
 
@@ -313,7 +321,7 @@ __global__ __launch_bounds__(kThreads) void rfft_kernel(const TIn* __restrict__ 
 template <int H, int G>
 __global__ __launch_bounds__(kThreads) void irfft_kernel(const float2* __restrict__ xf, float* __restrict__ x,
                                                          const float2* __restrict__ tw, int BC, int K, int M,
-                                                         float scale0, float scale_m, float scale_h) {
+                                                         float scale0, float scale_m, float scale_h, XfLayout xl) {
     constexpr int N = 2 * H, HP = H + 1;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -329,7 +337,7 @@ __global__ __launch_bounds__(kThreads) void irfft_kernel(const float2* __restric
         float2 a = make_float2(0.f, 0.f), b = make_float2(0.f, 0.f);
         if (bc < BC) {
             if (j < M) {
-                a = xf[((size_t)j * K + k) * BC + bc];
+                a = xf[((size_t)j * xl.sm + (size_t)k * xl.sk) * BC + bc];
                 const float s = (j == 0) ? scale0 : scale_m;
                 a.x *= s;
                 a.y *= s;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(kThreads) void irfft_kernel(const float2* __restric
             }
             const int jm = H - j;  // 1..H
             if (jm < M) {
-                b = xf[((size_t)jm * K + k) * BC + bc];
+                b = xf[((size_t)jm * xl.sm + (size_t)k * xl.sk) * BC + bc];
                 const float sb = (jm == H) ? scale_h : scale_m;
                 b.x *= sb;
                 b.y *= sb;
@@ -370,7 +378,7 @@ __global__ __launch_bounds__(kThreads) void irfft_kernel(const float2* __restric
 template <typename TIn>
 __global__ __launch_bounds__(kThreads) void rdft_generic_kernel(const TIn* __restrict__ x, float2* __restrict__ xf,
                                                                 const float2* __restrict__ tw, int BC, int K, int N,
-                                                                int M, float scale0, float scale_m, float scale_h) {
+                                                                int M, float scale0, float scale_m, float scale_h, XfLayout xl) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     float* row = reinterpret_cast<float*>(lds);  // N floats
     const int H = N / 2;
@@ -392,19 +400,19 @@ __global__ __launch_bounds__(kThreads) void rdft_generic_kernel(const TIn* __res
             im += row[n] * w.y;
         }
         const float s = (m == 0) ? scale0 : ((m == H) ? scale_h : scale_m);
-        xf[((size_t)m * K + k) * BC + bc] = make_float2(s * re, s * im);
+        xf[((size_t)m * xl.sm + (size_t)k * xl.sk) * BC + bc] = make_float2(s * re, s * im);
     }
 }
 
 __global__ __launch_bounds__(kThreads) void irdft_generic_kernel(const float2* __restrict__ xf, float* __restrict__ x,
                                                                  const float2* __restrict__ tw, int BC, int K, int N,
-                                                                 int M, float scale0, float scale_m, float scale_h) {
+                                                                 int M, float scale0, float scale_m, float scale_h, XfLayout xl) {
     extern __shared__ __attribute__((aligned(16))) float2 lds[];  // M modes
     const int H = N / 2;
     const float2* tw2 = tw + H;
     const int bc = blockIdx.x % BC, k = blockIdx.x / BC;
     for (int m = threadIdx.x; m < M; m += kThreads) {
-        float2 a = xf[((size_t)m * K + k) * BC + bc];
+        float2 a = xf[((size_t)m * xl.sm + (size_t)k * xl.sk) * BC + bc];
         const float s = (m == 0) ? scale0 : ((m == H) ? scale_h : 2.f * scale_m);
         a.x *= s;
         a.y *= s;
@@ -432,10 +440,10 @@ int launch_rfft(const void* x, int x_dtype, float* xf, const float* tw, int bc, 
     const size_t lds = sizeof(float2) * G * (H + 1);
     if (x_dtype == 0)
         hipLaunchKernelGGL((rfft_kernel<H, G, float>), grid, dim3(kThreads), lds, st, (const float*)x, (float2*)xf,
-                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl);
     else
         hipLaunchKernelGGL((rfft_kernel<H, G, __hip_bfloat16>), grid, dim3(kThreads), lds, st,
-                           (const __hip_bfloat16*)x, (float2*)xf, (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+                           (const __hip_bfloat16*)x, (float2*)xf, (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl);
     return 0;
 }
 
@@ -446,7 +454,7 @@ int launch_irfft(const float* xf, float* x, const float* tw, int bc, int nlat, i
     const dim3 grid((unsigned)(ntile * nlat));
     const size_t lds = sizeof(float2) * G * (H + 1);
     hipLaunchKernelGGL((irfft_kernel<H, G>), grid, dim3(kThreads), lds, st, (const float2*)xf, x, (const float2*)tw,
-                       bc, nlat, mmax, s0, sm, sh);
+                       bc, nlat, mmax, s0, sm, sh, g_xl);
     return 0;
 }
 
@@ -460,6 +468,13 @@ int launch_irfft(const float* xf, float* x, const float* tw, int bc, int nlat, i
 
 extern "C" int mk_rfft(const void* x, int x_dtype, float* xf, const float* twiddles, int bc, int nlat, int nlon,
                        int mmax, float scale0, float scale_m, float scale_h, void* stream) {
+    return mk_rfft_ex(x, x_dtype, xf, twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, 0, stream);
+}
+
+extern "C" int mk_rfft_ex(const void* x, int x_dtype, float* xf, const float* twiddles, int bc, int nlat, int nlon,
+                          int mmax, float scale0, float scale_m, float scale_h, int xf_layout, void* stream) {
+    MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
+    g_xl = xf_layout ? XfLayout{1, mmax} : XfLayout{nlat, 1};
     MK_REQUIRE(x && xf && twiddles, "null pointer");
     MK_REQUIRE(bc > 0 && nlat > 0 && nlon >= 2 && nlon % 2 == 0, "bad sizes (nlon must be even)");
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "mmax out of range");
@@ -485,11 +500,11 @@ extern "C" int mk_rfft(const void* x, int x_dtype, float* xf, const float* twidd
             const size_t lds = sizeof(float) * nlon;
             if (x_dtype == 0)
                 hipLaunchKernelGGL((rdft_generic_kernel<float>), grid, dim3(kThreads), lds, st, (const float*)x,
-                                   (float2*)xf, (const float2*)twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h);
+                                   (float2*)xf, (const float2*)twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, g_xl);
             else
                 hipLaunchKernelGGL((rdft_generic_kernel<__hip_bfloat16>), grid, dim3(kThreads), lds, st,
                                    (const __hip_bfloat16*)x, (float2*)xf, (const float2*)twiddles, bc, nlat, nlon,
-                                   mmax, scale0, scale_m, scale_h);
+                                   mmax, scale0, scale_m, scale_h, g_xl);
         }
     }
     MK_LAUNCH_CHECK();
@@ -498,6 +513,13 @@ extern "C" int mk_rfft(const void* x, int x_dtype, float* xf, const float* twidd
 
 extern "C" int mk_irfft(const float* xf, void* xout, int x_dtype, const float* twiddles, int bc, int nlat, int nlon,
                         int mmax, float scale0, float scale_m, float scale_h, void* stream) {
+    return mk_irfft_ex(xf, xout, x_dtype, twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, 0, stream);
+}
+
+extern "C" int mk_irfft_ex(const float* xf, void* xout, int x_dtype, const float* twiddles, int bc, int nlat, int nlon,
+                           int mmax, float scale0, float scale_m, float scale_h, int xf_layout, void* stream) {
+    MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
+    g_xl = xf_layout ? XfLayout{1, mmax} : XfLayout{nlat, 1};
     float* x = (float*)xout;
     MK_REQUIRE(x_dtype == 0 || x_dtype == 1, "x_dtype must be 0 (fp32) or 1 (bf16)");
     MK_REQUIRE(x_dtype == 0 || (!fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440)),
@@ -525,7 +547,7 @@ extern "C" int mk_irfft(const float* xf, void* xout, int x_dtype, const float* t
             const dim3 grid((unsigned)(nlat * bc));
             const size_t lds = sizeof(float2) * mmax;
             hipLaunchKernelGGL(irdft_generic_kernel, grid, dim3(kThreads), lds, st, (const float2*)xf, x,
-                               (const float2*)twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h);
+                               (const float2*)twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, g_xl);
         }
     }
     MK_LAUNCH_CHECK();

@@ -97,7 +97,7 @@ template <> struct InVec<__hip_bfloat16> {
 template <int S, typename TIn>
 __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restrict__ x, float2* __restrict__ xf,
                                                               const float2* __restrict__ tw, int BC, int K, int M,
-                                                              float scale0, float scale_m, float scale_h, int exp) {
+                                                              float scale0, float scale_m, float scale_h, int exp, XfLayout xl) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2, E = InVec<TIn>::E;
     // staging unit: S consecutive vectors of E reals = E reals (E/2 complex) of every sub-sequence
     constexpr int GPR = N / (S * E), NGRP = G * GPR, IT = (NGRP + STHREADS - 1) / STHREADS;
@@ -196,11 +196,11 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
         }
         if (mp < M) {
             const float sc = (mp == 0) ? scale0 : scale_m;
-            xf[((size_t)mp * K + k) * BC + bc] = make_float2(sc * acc0.x, sc * acc0.y);
+            xf[((size_t)mp * xl.sm + (size_t)k * xl.sk) * BC + bc] = make_float2(sc * acc0.x, sc * acc0.y);
         }
         if (m1 != mp && m1 < M) {
             const float sc = (m1 == HH) ? scale_h : scale_m;
-            xf[((size_t)m1 * K + k) * BC + bc] = make_float2(sc * acc1.x, sc * acc1.y);
+            xf[((size_t)m1 * xl.sm + (size_t)k * xl.sk) * BC + bc] = make_float2(sc * acc1.x, sc * acc1.y);
         }
     }
 }
@@ -225,7 +225,7 @@ template <> struct OutVec<__hip_bfloat16> {
 template <int S, typename TOut>
 __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
-                                                               float scale0, float scale_m, float scale_h) {
+                                                               float scale0, float scale_m, float scale_h, XfLayout xl) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
     const int tid = threadIdx.x;
@@ -262,8 +262,8 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
             xa[it] = make_float2(0.f, 0.f);
             xb[it] = make_float2(0.f, 0.f);
             if (idx < G * NPAIR && bc < BC) {
-                if (jp < M) xa[it] = xf[((size_t)jp * K + k) * BC + bc];
-                if (j1 < M) xb[it] = xf[((size_t)j1 * K + k) * BC + bc];
+                if (jp < M) xa[it] = xf[((size_t)jp * xl.sm + (size_t)k * xl.sk) * BC + bc];
+                if (j1 < M) xb[it] = xf[((size_t)j1 * xl.sm + (size_t)k * xl.sk) * BC + bc];
             }
         }
     };
@@ -383,10 +383,10 @@ int launch_rfft_split(const void* x, int x_dtype, float* xf, const float* tw, in
     const size_t lds = sizeof(float2) * SLDS_F2;
     if (x_dtype == 0)
         hipLaunchKernelGGL((rfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float*)x, (float2*)xf,
-                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh, fft_exp());
+                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh, fft_exp(), g_xl);
     else
         hipLaunchKernelGGL((rfft_split_kernel<S, __hip_bfloat16>), grid, dim3(STHREADS), lds, st,
-                           (const __hip_bfloat16*)x, (float2*)xf, (const float2*)tw, bc, nlat, mmax, s0, sm, sh, fft_exp());
+                           (const __hip_bfloat16*)x, (float2*)xf, (const float2*)tw, bc, nlat, mmax, s0, sm, sh, fft_exp(), g_xl);
     return 0;
 }
 
@@ -398,10 +398,10 @@ int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, i
     const size_t lds = sizeof(float2) * SLDS_F2;
     if (x_dtype == 0)
         hipLaunchKernelGGL((irfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (float*)x,
-                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl);
     else
         hipLaunchKernelGGL((irfft_split_kernel<S, __hip_bfloat16>), grid, dim3(STHREADS), lds, st, (const float2*)xf,
-                           (__hip_bfloat16*)x, (const float2*)tw, bc, nlat, mmax, s0, sm, sh);
+                           (__hip_bfloat16*)x, (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl);
     return 0;
 }
 

@@ -420,6 +420,7 @@ struct LegX3Params {
     int RT;   // analysis layout: 128-row tiles per m (rows l = m + 128 rt + r);  synthesis layout: k tiles
     int KC;   // analysis layout: 32-k chunks;                                   synthesis layout: 32-l chunks
     int tiles_n;
+    int kmajor;   // layout of the Fourier rows: 0 = xf[m][k][:], 1 = xf[k][m][:] (latitude major, distributed SHT)
     int exp;  // ablation switches (MK_X3_EXP): 1 no prefetch loads, 2 no staging stores, 4 no MFMAs -- wrong results
 };
 
@@ -435,8 +436,8 @@ __global__ __launch_bounds__(XT, 3) void legendre_fwd_x3_kernel(LegX3Params p) {
     PresplitStager as;
     as.base = p.tab + ((long long)mg * p.RT + t.tm) * p.KC * XCHUNK;
     TransStager bs;
-    bs.base = p.src + (long long)m * p.K * p.N2 + n0;
-    bs.ldk = p.N2;
+    bs.base = p.src + (p.kmajor ? (long long)m * p.N2 : (long long)m * p.K * p.N2) + n0;
+    bs.ldk = p.kmajor ? (long long)p.Mloc * p.N2 : (long long)p.N2;
     bs.k_lo = 0;
     bs.k_hi = p.K;
     bs.cvalid = p.N2 - n0;
@@ -462,8 +463,9 @@ __global__ __launch_bounds__(XT, 3) void legendre_inv_x3_kernel(LegX3Params p) {
     bs.k_hi = p.L;
     bs.cvalid = p.N2 - n0;
     const int kt0 = mg >> 5;
-    x3_tile<1>(as, bs, kt0 < p.KC ? kt0 : p.KC, p.KC, p.K - k0, p.N2 - n0, p.dst + ((long long)m * p.K + k0) * p.N2 + n0,
-            (long long)p.N2, lds_x3, p.exp);
+    float* cb = p.kmajor ? p.dst + ((long long)k0 * p.Mloc + m) * p.N2 + n0 : p.dst + ((long long)m * p.K + k0) * p.N2 + n0;
+    x3_tile<1>(as, bs, kt0 < p.KC ? kt0 : p.KC, p.KC, p.K - k0, p.N2 - n0, cb,
+               p.kmajor ? (long long)p.Mloc * p.N2 : (long long)p.N2, lds_x3, p.exp);
 }
 
 // ---------------------------------------------------------------------------
@@ -619,8 +621,9 @@ extern "C" int mk_legendre_x3_split(const float* tab, void* out, int nlat, int l
 }
 
 static int legendre_x3_launch(bool fwd, const float* src, const void* tab, float* dst, int bc, int nlat, int lmax,
-                              int mmax_loc, int m_off, hipStream_t st) {
+                              int mmax_loc, int m_off, int kmajor, hipStream_t st) {
     LegX3Params p;
+    p.kmajor = kmajor;
     p.src = src;
     p.tab = (const char*)tab;
     p.dst = dst;
@@ -641,12 +644,30 @@ static int legendre_x3_launch(bool fwd, const float* src, const void* tab, float
     return 0;
 }
 
-extern "C" int mk_legendre_fwd_x3(const float* xf, const void* tab_x3, float* c, int bc, int nlat, int lmax, int mmax_loc,
-                                  int m_off, int mmax_glob, void* stream) {
+extern "C" int mk_legendre_fwd_x3_ex(const float* xf, const void* tab_x3, float* c, int bc, int nlat, int lmax,
+                                     int mmax_loc, int m_off, int mmax_glob, int xf_layout, void* stream) {
     MK_REQUIRE(xf && tab_x3 && c, "null pointer");
     MK_REQUIRE(bc > 0 && nlat > 0 && lmax > 0 && mmax_loc > 0, "bad sizes");
     MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
-    MK_REQUIRE(legendre_x3_launch(true, xf, tab_x3, c, bc, nlat, lmax, mmax_loc, m_off, (hipStream_t)stream) == 0,
+    MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
+    MK_REQUIRE(legendre_x3_launch(true, xf, tab_x3, c, bc, nlat, lmax, mmax_loc, m_off, xf_layout, (hipStream_t)stream) == 0,
+               "grid too large");
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_legendre_fwd_x3(const float* xf, const void* tab_x3, float* c, int bc, int nlat, int lmax, int mmax_loc,
+                                  int m_off, int mmax_glob, void* stream) {
+    return mk_legendre_fwd_x3_ex(xf, tab_x3, c, bc, nlat, lmax, mmax_loc, m_off, mmax_glob, 0, stream);
+}
+
+extern "C" int mk_legendre_inv_x3_ex(const float* c, const void* tab_x3, float* xf, int bc, int nlat, int lmax,
+                                     int mmax_loc, int m_off, int mmax_glob, int xf_layout, void* stream) {
+    MK_REQUIRE(xf && tab_x3 && c, "null pointer");
+    MK_REQUIRE(bc > 0 && nlat > 0 && lmax > 0 && mmax_loc > 0, "bad sizes");
+    MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
+    MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
+    MK_REQUIRE(legendre_x3_launch(false, c, tab_x3, xf, bc, nlat, lmax, mmax_loc, m_off, xf_layout, (hipStream_t)stream) == 0,
                "grid too large");
     MK_LAUNCH_CHECK();
     return 0;
@@ -654,13 +675,7 @@ extern "C" int mk_legendre_fwd_x3(const float* xf, const void* tab_x3, float* c,
 
 extern "C" int mk_legendre_inv_x3(const float* c, const void* tab_x3, float* xf, int bc, int nlat, int lmax, int mmax_loc,
                                   int m_off, int mmax_glob, void* stream) {
-    MK_REQUIRE(xf && tab_x3 && c, "null pointer");
-    MK_REQUIRE(bc > 0 && nlat > 0 && lmax > 0 && mmax_loc > 0, "bad sizes");
-    MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
-    MK_REQUIRE(legendre_x3_launch(false, c, tab_x3, xf, bc, nlat, lmax, mmax_loc, m_off, (hipStream_t)stream) == 0,
-               "grid too large");
-    MK_LAUNCH_CHECK();
-    return 0;
+    return mk_legendre_inv_x3_ex(c, tab_x3, xf, bc, nlat, lmax, mmax_loc, m_off, mmax_glob, 0, stream);
 }
 
 static int dh_x3_check(const void* a, const void* b, const void* c, int lloc, int mloc, int batch, int cin, int cout,

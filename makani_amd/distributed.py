@@ -144,6 +144,17 @@ class DistributedRealSHT(_DistSHTBase):
     def forward_packed(self, x):
         """x [B, C, nlat_loc, nlon_loc] -> spectrum [l_loc, m_loc, B*C] (private layout)."""
         B, C = x.shape[0], x.shape[1]
+        if self.comm_size_azimuth == 1 and self.comm_size_polar > 1 and ops.SPECTRAL_GEMM == "bf16x3":
+            # latitude-major Fourier rows [K, M, B, C]: the latitude all-to-all gathers the OUTERMOST axis, so the
+            # received chunks are the Legendre operand as they arrive (no concatenate copy)
+            xf = ops.rfft(x.reshape(B * C, x.shape[2], self.nlon).contiguous(), self.twiddles, self.mmax, True)
+            xf = xf.view(-1, self.mmax, B, C)                                     # [K_loc, M, B, C]
+            xf = distributed_transpose_polar.apply(xf, (3, 0), self.lat_shapes)    # [K, M, B, C_h]
+            Ch = xf.shape[3]
+            c = ops.legendre_fwd(xf.reshape(self.nlat, self.mmax, B * Ch), self.weights, self.lmax, self.m_off, True)
+            c = c.view(self.lmax, -1, B, Ch)
+            c = distributed_transpose_polar.apply(c, (0, 3), compute_split_shapes(C, self.comm_size_polar))
+            return c.reshape(c.shape[0], c.shape[1], B * C).contiguous()
         if self.comm_size_azimuth > 1:      # make longitude local, split channels over w
             x = distributed_transpose_azimuth.apply(x, (1, -1), self.lon_shapes)
         Cw = x.shape[1]
@@ -181,6 +192,15 @@ class DistributedInverseRealSHT(_DistSHTBase):
         """spectrum [l_loc, m_loc, B*C] -> x [B, C, nlat_loc, nlon_loc]."""
         C = c.shape[2] // B
         c = c.view(c.shape[0], c.shape[1], B, C)
+        if self.comm_size_azimuth == 1 and self.comm_size_polar > 1 and ops.SPECTRAL_GEMM == "bf16x3":
+            # latitude-major Fourier rows: the latitude all-to-all splits the OUTERMOST axis (no pack copy)
+            c = distributed_transpose_polar.apply(c, (3, 0), self.l_shapes)
+            Ch = c.shape[3]
+            xf = ops.legendre_inv(c.reshape(self.lmax, c.shape[1], B * Ch).contiguous(), self.pct, self.nlat, self.m_off, True)
+            xf = xf.view(self.nlat, -1, B, Ch)                                    # [K, M, B, C_h]
+            xf = distributed_transpose_polar.apply(xf, (0, 3), compute_split_shapes(C, self.comm_size_polar))
+            x = ops.irfft(xf.reshape(xf.shape[0], self.mmax, B * C).contiguous(), self.twiddles, self.nlon, out_dtype, True)
+            return x.view(B, C, -1, self.nlon)
         if self.comm_size_polar > 1:        # make degrees local, split channels over h
             c = distributed_transpose_polar.apply(c, (3, 0), self.l_shapes)
         Ch = c.shape[3]

@@ -70,8 +70,8 @@ def fft_twiddles(nlon):
 # ----------------------------------------------------------------------------
 # raw (non-differentiable) launches
 # ----------------------------------------------------------------------------
-def rfft_raw(x, twiddles, mmax, s0, sm, sh):
-    """x real [BC, K, N] (fp32 or bf16) -> xf complex64 [mmax, K, BC]."""
+def rfft_raw(x, twiddles, mmax, s0, sm, sh, kmajor=False):
+    """x real [BC, K, N] (fp32 or bf16) -> xf complex64 [mmax, K, BC], or [K, mmax, BC] with ``kmajor``."""
     _need_cuda(x, twiddles)
     assert x.dim() == 3 and x.is_contiguous()
     bc, k, n = x.shape
@@ -81,9 +81,9 @@ def rfft_raw(x, twiddles, mmax, s0, sm, sh):
         dt = 1
     else:
         raise TypeError(f"mk_rfft: unsupported dtype {x.dtype}")
-    xf = torch.empty(mmax, k, bc, dtype=torch.complex64, device=x.device)
-    _lib.check(_lib.load().mk_rfft(x.data_ptr(), dt, xf.data_ptr(), twiddles.data_ptr(), bc, k, n, mmax,
-                                   s0, sm, sh, _stream()), "mk_rfft")
+    xf = torch.empty((k, mmax, bc) if kmajor else (mmax, k, bc), dtype=torch.complex64, device=x.device)
+    _lib.check(_lib.load().mk_rfft_ex(x.data_ptr(), dt, xf.data_ptr(), twiddles.data_ptr(), bc, k, n, mmax,
+                                      s0, sm, sh, int(bool(kmajor)), _stream()), "mk_rfft")
     return xf
 
 
@@ -92,15 +92,19 @@ def irfft_bf16_rows(nlon, mmax):
     return nlon in (480, 1440) and mmax <= 241
 
 
-def irfft_raw(xf, twiddles, nlon, s0, sm, sh, out_dtype=torch.float32):
-    """xf complex64 [M, K, BC] -> x [BC, K, nlon] in fp32, or bf16 where the kernel fuses the cast."""
+def irfft_raw(xf, twiddles, nlon, s0, sm, sh, out_dtype=torch.float32, kmajor=False):
+    """xf complex64 [M, K, BC] ([K, M, BC] with ``kmajor``) -> x [BC, K, nlon] in fp32, or bf16 where the kernel
+    fuses the cast."""
     _need_cuda(xf, twiddles)
     assert xf.dim() == 3 and xf.is_contiguous() and xf.dtype == torch.complex64
-    m, k, bc = xf.shape
+    if kmajor:
+        k, m, bc = xf.shape
+    else:
+        m, k, bc = xf.shape
     fused = out_dtype == torch.bfloat16 and irfft_bf16_rows(nlon, m)
     x = torch.empty(bc, k, nlon, dtype=torch.bfloat16 if fused else torch.float32, device=xf.device)
-    _lib.check(_lib.load().mk_irfft(xf.data_ptr(), x.data_ptr(), 1 if fused else 0, twiddles.data_ptr(), bc, k, nlon, m,
-                                    s0, sm, sh, _stream()), "mk_irfft")
+    _lib.check(_lib.load().mk_irfft_ex(xf.data_ptr(), x.data_ptr(), 1 if fused else 0, twiddles.data_ptr(), bc, k, nlon, m,
+                                       s0, sm, sh, int(bool(kmajor)), _stream()), "mk_irfft")
     return x if x.dtype == out_dtype else x.to(out_dtype)
 
 
@@ -135,36 +139,43 @@ def legendre_x3_image(table, nlat, inverse):
     return img
 
 
-def legendre_fwd_raw(xf, table, lmax, m_off=0, mode=None):
-    """xf [Mloc, K, BC] -> spectrum [lmax, Mloc, BC]; rows l < m are left unwritten."""
+def legendre_fwd_raw(xf, table, lmax, m_off=0, mode=None, kmajor=False):
+    """xf [Mloc, K, BC] ([K, Mloc, BC] with ``kmajor``: bf16x3 kernels only) -> spectrum [lmax, Mloc, BC]; rows l < m
+    are left unwritten."""
     _need_cuda(xf, table)
     assert xf.is_contiguous() and xf.dtype == torch.complex64 and table.dtype == torch.float32
-    mloc, k, bc = xf.shape
+    if kmajor:
+        k, mloc, bc = xf.shape
+        mode = "bf16x3"
+    else:
+        mloc, k, bc = xf.shape
     mg, lt, kp = table.shape
     assert lt == lmax and kp == legendre_kpad(k), "Legendre table does not match the operand"
     c = torch.empty(lmax, mloc, bc, dtype=torch.complex64, device=xf.device)
     if _gemm_mode(mode) == "bf16x3":
         img = legendre_x3_image(table, k, 0)
-        _lib.check(_lib.load().mk_legendre_fwd_x3(xf.data_ptr(), img.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
-                                                  m_off, mg, _stream()), "mk_legendre_fwd_x3")
+        _lib.check(_lib.load().mk_legendre_fwd_x3_ex(xf.data_ptr(), img.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
+                                                     m_off, mg, int(bool(kmajor)), _stream()), "mk_legendre_fwd_x3")
     else:
         _lib.check(_lib.load().mk_legendre_fwd(xf.data_ptr(), table.data_ptr(), c.data_ptr(), bc, k, lmax, mloc,
                                                m_off, mg, _stream()), "mk_legendre_fwd")
     return c
 
 
-def legendre_inv_raw(c, table, nlat, m_off=0, mode=None):
-    """spectrum [L, Mloc, BC] -> xf [Mloc, nlat, BC]."""
+def legendre_inv_raw(c, table, nlat, m_off=0, mode=None, kmajor=False):
+    """spectrum [L, Mloc, BC] -> xf [Mloc, nlat, BC] ([nlat, Mloc, BC] with ``kmajor``: bf16x3 kernels only)."""
     _need_cuda(c, table)
     assert c.is_contiguous() and c.dtype == torch.complex64 and table.dtype == torch.float32
     lmax, mloc, bc = c.shape
     mg, lt, kp = table.shape
     assert lt == lmax and kp == legendre_kpad(nlat), "Legendre table does not match the operand"
-    xf = torch.empty(mloc, nlat, bc, dtype=torch.complex64, device=c.device)
+    xf = torch.empty((nlat, mloc, bc) if kmajor else (mloc, nlat, bc), dtype=torch.complex64, device=c.device)
+    if kmajor:
+        mode = "bf16x3"
     if _gemm_mode(mode) == "bf16x3":
         img = legendre_x3_image(table, nlat, 1)
-        _lib.check(_lib.load().mk_legendre_inv_x3(c.data_ptr(), img.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
-                                                  m_off, mg, _stream()), "mk_legendre_inv_x3")
+        _lib.check(_lib.load().mk_legendre_inv_x3_ex(c.data_ptr(), img.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
+                                                     m_off, mg, int(bool(kmajor)), _stream()), "mk_legendre_inv_x3")
     else:
         _lib.check(_lib.load().mk_legendre_inv(c.data_ptr(), table.data_ptr(), xf.data_ptr(), bc, nlat, lmax, mloc,
                                                m_off, mg, _stream()), "mk_legendre_inv")
@@ -320,64 +331,66 @@ class _RFFT(torch.autograd.Function):
     """x [BC, K, N] -> xf [mmax, K, BC] = 2 pi rfft(x, norm="forward")[..., :mmax] (K1)."""
 
     @staticmethod
-    def forward(ctx, x, twiddles, mmax):
+    def forward(ctx, x, twiddles, mmax, kmajor=False):
         ctx.save_for_backward(twiddles)
         ctx.nlon = x.shape[-1]
         ctx.in_dtype = x.dtype
+        ctx.kmajor = kmajor
         s = 2.0 * math.pi / ctx.nlon
-        return rfft_raw(x, twiddles, mmax, s, s, s)
+        return rfft_raw(x, twiddles, mmax, s, s, s, kmajor)
 
     @staticmethod
     def backward(ctx, gxf):
         (tw,) = ctx.saved_tensors
         n = ctx.nlon
-        gx = irfft_raw(gxf.contiguous(), tw, n, 2.0 * math.pi / n, math.pi / n, 2.0 * math.pi / n, ctx.in_dtype)
-        return gx, None, None
+        gx = irfft_raw(gxf.contiguous(), tw, n, 2.0 * math.pi / n, math.pi / n, 2.0 * math.pi / n, ctx.in_dtype, ctx.kmajor)
+        return gx, None, None, None
 
 
 class _IRFFT(torch.autograd.Function):
     """xf [M, K, BC] -> x [BC, K, nlon] = irfft(xf, n=nlon, norm="forward") (K4)."""
 
     @staticmethod
-    def forward(ctx, xf, twiddles, nlon, out_dtype):
+    def forward(ctx, xf, twiddles, nlon, out_dtype, kmajor=False):
         ctx.save_for_backward(twiddles)
-        ctx.mmax = xf.shape[0]
-        return irfft_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0, out_dtype)
+        ctx.mmax = xf.shape[1] if kmajor else xf.shape[0]
+        ctx.kmajor = kmajor
+        return irfft_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0, out_dtype, kmajor)
 
     @staticmethod
     def backward(ctx, gx):
         (tw,) = ctx.saved_tensors
         if gx.dtype not in (torch.float32, torch.bfloat16):
             gx = gx.float()
-        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0), None, None, None
+        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0, ctx.kmajor), None, None, None, None
 
 
 class _LegendreFwd(torch.autograd.Function):
     """xf [Mloc, K, BC] -> c [L, Mloc, BC] with table[m_off + m] (K2)."""
 
     @staticmethod
-    def forward(ctx, xf, table, lmax, m_off):
+    def forward(ctx, xf, table, lmax, m_off, kmajor=False):
         ctx.table = table   # constant buffer; the python object carries the cached bf16x3 images
-        ctx.nlat, ctx.m_off = xf.shape[1], m_off
-        return legendre_fwd_raw(xf, table, lmax, m_off)
+        ctx.nlat, ctx.m_off, ctx.kmajor = xf.shape[0] if kmajor else xf.shape[1], m_off, kmajor
+        return legendre_fwd_raw(xf, table, lmax, m_off, kmajor=kmajor)
 
     @staticmethod
     def backward(ctx, gc):
-        return legendre_inv_raw(gc.contiguous(), ctx.table, ctx.nlat, ctx.m_off), None, None, None
+        return legendre_inv_raw(gc.contiguous(), ctx.table, ctx.nlat, ctx.m_off, kmajor=ctx.kmajor), None, None, None, None
 
 
 class _LegendreInv(torch.autograd.Function):
     """c [L, Mloc, BC] -> xf [Mloc, K, BC] with table[m_off + m] (K3)."""
 
     @staticmethod
-    def forward(ctx, c, table, nlat, m_off):
+    def forward(ctx, c, table, nlat, m_off, kmajor=False):
         ctx.table = table
-        ctx.lmax, ctx.m_off = c.shape[0], m_off
-        return legendre_inv_raw(c, table, nlat, m_off)
+        ctx.lmax, ctx.m_off, ctx.kmajor = c.shape[0], m_off, kmajor
+        return legendre_inv_raw(c, table, nlat, m_off, kmajor=kmajor)
 
     @staticmethod
     def backward(ctx, gxf):
-        return legendre_fwd_raw(gxf.contiguous(), ctx.table, ctx.lmax, ctx.m_off), None, None, None
+        return legendre_fwd_raw(gxf.contiguous(), ctx.table, ctx.lmax, ctx.m_off, kmajor=ctx.kmajor), None, None, None, None
 
 
 class _SpecPack(torch.autograd.Function):
@@ -425,20 +438,20 @@ class _Dhconv(torch.autograd.Function):
         return gx, gw, None, None, None
 
 
-def rfft(x, twiddles, mmax):
-    return _RFFT.apply(x, twiddles, mmax)
+def rfft(x, twiddles, mmax, kmajor=False):
+    return _RFFT.apply(x, twiddles, mmax, kmajor)
 
 
-def irfft(xf, twiddles, nlon, out_dtype=torch.float32):
-    return _IRFFT.apply(xf, twiddles, nlon, out_dtype)
+def irfft(xf, twiddles, nlon, out_dtype=torch.float32, kmajor=False):
+    return _IRFFT.apply(xf, twiddles, nlon, out_dtype, kmajor)
 
 
-def legendre_fwd(xf, table, lmax, m_off=0):
-    return _LegendreFwd.apply(xf, table, lmax, m_off)
+def legendre_fwd(xf, table, lmax, m_off=0, kmajor=False):
+    return _LegendreFwd.apply(xf, table, lmax, m_off, kmajor)
 
 
-def legendre_inv(c, table, nlat, m_off=0):
-    return _LegendreInv.apply(c, table, nlat, m_off)
+def legendre_inv(c, table, nlat, m_off=0, kmajor=False):
+    return _LegendreInv.apply(c, table, nlat, m_off, kmajor)
 
 
 def spec_pack(c_std, l_off=0, m_off=0):

@@ -57,8 +57,9 @@ class RealSHT(_SHTBase):
 
     def forward_packed(self, x3):
         """x3 [BC, nlat, nlon] (fp32 or bf16, contiguous) -> spectrum [lmax, mmax, BC]."""
-        xf = ops.rfft(x3, self.twiddles, self.mmax)
-        return ops.legendre_fwd(xf, self.weights, self.lmax, 0)
+        km = ops.SPECTRAL_GEMM == "bf16x3"   # latitude-major Fourier rows [K, M, BC]: the FFT writes them 10 % faster
+        xf = ops.rfft(x3, self.twiddles, self.mmax, km)
+        return ops.legendre_fwd(xf, self.weights, self.lmax, 0, km)
 
     def forward(self, x):
         if x.shape[-2] != self.nlat or x.shape[-1] != self.nlon:
@@ -79,8 +80,9 @@ class InverseRealSHT(_SHTBase):
 
     def inverse_packed(self, c, out_dtype=torch.float32):
         """spectrum [lmax, mmax, BC] -> x [BC, nlat, nlon] (fp32, or bf16 rows straight from the FFT kernel)."""
-        xf = ops.legendre_inv(c, self.pct, self.nlat, 0)
-        return ops.irfft(xf, self.twiddles, self.nlon, out_dtype)
+        km = ops.SPECTRAL_GEMM == "bf16x3"
+        xf = ops.legendre_inv(c, self.pct, self.nlat, 0, km)
+        return ops.irfft(xf, self.twiddles, self.nlon, out_dtype, km)
 
     def forward(self, x):
         if x.shape[-2] != self.lmax or x.shape[-1] != self.mmax:

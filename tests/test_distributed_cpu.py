@@ -33,22 +33,26 @@ def _free_port():
 def _install_cpu_ops():
     from makani_amd import ops
 
-    def rfft(x, tw, mmax):
-        y = 2.0 * math.pi * torch.fft.rfft(x.float(), dim=-1, norm="forward")[..., :mmax]
-        return y.permute(2, 1, 0).contiguous()
+    # kmajor: the latitude-major layout [K, M, BC] of the Fourier rows (distributed.py), else [M, K, BC]
+    def rfft(x, tw, mmax, kmajor=False):
+        y = 2.0 * math.pi * torch.fft.rfft(x.float(), dim=-1, norm="forward")[..., :mmax]      # [BC, K, M]
+        return (y.permute(1, 2, 0) if kmajor else y.permute(2, 1, 0)).contiguous()
 
-    def irfft(xf, tw, nlon, out_dtype=torch.float32):
-        return torch.fft.irfft(xf.permute(2, 1, 0), n=nlon, dim=-1, norm="forward").contiguous().to(out_dtype)
+    def irfft(xf, tw, nlon, out_dtype=torch.float32, kmajor=False):
+        xs = xf.permute(2, 0, 1) if kmajor else xf.permute(2, 1, 0)                             # [BC, K, M]
+        return torch.fft.irfft(xs, n=nlon, dim=-1, norm="forward").contiguous().to(out_dtype)
 
-    def legendre_fwd(xf, table, lmax, m_off=0):
+    def legendre_fwd(xf, table, lmax, m_off=0, kmajor=False):
+        if kmajor:
+            xf = xf.permute(1, 0, 2)
         mloc, k, _ = xf.shape
         t = table[m_off:m_off + mloc, :, :k].to(xf.dtype)
         return torch.einsum("mlk,mkn->lmn", t, xf).contiguous()
 
-    def legendre_inv(c, table, nlat, m_off=0):
+    def legendre_inv(c, table, nlat, m_off=0, kmajor=False):
         mloc = c.shape[1]
         t = table[m_off:m_off + mloc, :, :nlat].to(c.dtype)
-        return torch.einsum("mlk,lmn->mkn", t, c).contiguous()
+        return torch.einsum("mlk,lmn->kmn" if kmajor else "mlk,lmn->mkn", t, c).contiguous()
 
     def spec_pack(c_std, l_off=0, m_off=0):
         return c_std.permute(1, 2, 0).contiguous()

@@ -60,8 +60,14 @@ def _shard(x, dim, name):
 def _body_sht(dev):
     from makani_amd.distributed import DistributedRealSHT, DistributedInverseRealSHT
     from oracle import spectral as osp
+    for nlat, nlon, lmax, mmax, B, C in ((91, 180, 30, 31, 2, 6), (33, 480, 32, 33, 1, 8)):   # planned / split FFT kernels
+        _sht_case(dev, nlat, nlon, lmax, mmax, B, C)
+
+
+def _sht_case(dev, nlat, nlon, lmax, mmax, B, C):
+    from makani_amd.distributed import DistributedRealSHT, DistributedInverseRealSHT
+    from oracle import spectral as osp
     torch.manual_seed(333)
-    nlat, nlon, lmax, mmax, B, C = 91, 180, 30, 31, 2, 6
     f = DistributedRealSHT(nlat, nlon, lmax, mmax, "equiangular").to(dev)
     fi = DistributedInverseRealSHT(nlat, nlon, lmax, mmax, "equiangular").to(dev)
     fo, fio = osp.TorchRealSHT(nlat, nlon, lmax, mmax, "equiangular"), osp.TorchInverseRealSHT(nlat, nlon, lmax, mmax, "equiangular")

@@ -401,3 +401,37 @@ def test_diag_contract_fwd_bwd(dev, B, I, O, L, M):
     assert rel(y.detach().cpu().numpy(), yr.detach().numpy()) < TOL
     assert rel(gx.cpu().numpy(), gxr.numpy()) < TOL
     assert rel(gw.cpu().numpy(), gwr.numpy()) < TOL
+
+
+# --------------------------------------------------------------------------- latitude-major Fourier rows (distributed SHT)
+@pytest.mark.parametrize("nlat,nlon,mmax,bc", [(9, 480, 33, 5), (7, 1440, 241, 3), (6, 64, 20, 4), (5, 30, 16, 2)])
+def test_fft_latitude_major_layout(dev, nlat, nlon, mmax, bc):
+    """xf_layout = 1 ([K][M][BC]) holds exactly the numbers of the default [M][K][BC] layout, split / planned / generic kernels."""
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(bc, nlat, nlon, generator=g).to(dev)
+    tw = ops.fft_twiddles(nlon).to(dev)
+    s = 2 * math.pi / nlon
+    a = ops.rfft_raw(x, tw, mmax, s, s, s)
+    b = ops.rfft_raw(x, tw, mmax, s, s, s, kmajor=True)
+    assert tuple(b.shape) == (nlat, mmax, bc) and torch.equal(a.permute(1, 0, 2), b)
+    y0 = ops.irfft_raw(a, tw, nlon, 1.0, 1.0, 1.0)
+    y1 = ops.irfft_raw(b, tw, nlon, 1.0, 1.0, 1.0, kmajor=True)
+    assert torch.equal(y0, y1)
+
+
+@pytest.mark.parametrize("grid,nlat,lmax,mmax,bc", [("equiangular", 33, 16, 17, 3), ("legendre-gauss", 240, 240, 241, 6),
+                                                     ("equiangular", 65, 70, 40, 66)])
+def test_legendre_latitude_major_layout(dev, grid, nlat, lmax, mmax, bc):
+    from makani_amd import ops
+    rng = np.random.default_rng(9)
+    tab = ops.legendre_table(grid, nlat, lmax, mmax, True).to(dev)
+    xf = torch.from_numpy((rng.standard_normal((mmax, nlat, bc)) + 1j * rng.standard_normal((mmax, nlat, bc))).astype(np.complex64)).to(dev)
+    mask = torch.from_numpy(tril_mask(lmax, mmax)).to(dev)[:, :, None]
+    c0 = ops.legendre_fwd_raw(xf, tab, lmax, mode="bf16x3")
+    c1 = ops.legendre_fwd_raw(xf.permute(1, 0, 2).contiguous(), tab, lmax, kmajor=True)
+    assert torch.equal(torch.where(mask, c0, 0), torch.where(mask, c1, 0))
+    cm = torch.where(mask, c0, 0)
+    y0 = ops.legendre_inv_raw(cm, tab, nlat, mode="bf16x3")
+    y1 = ops.legendre_inv_raw(cm, tab, nlat, kmajor=True)
+    assert tuple(y1.shape) == (nlat, mmax, bc) and torch.equal(y0.permute(1, 0, 2), y1)

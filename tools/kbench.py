@@ -74,11 +74,17 @@ def main():
             report("rfft", shape, ms, b, fft_bytes, "byte")
             ms, b = timeit(lambda: ops.rfft_raw(xb, tw, M, s, s, s), args.iters)
             report("rfft(bf16 in)", shape, ms, b, K * bc * (2 * N + 8 * M), "byte")
+            ms, b = timeit(lambda: ops.rfft_raw(xb, tw, M, s, s, s, kmajor=True), args.iters)
+            report("rfft(bf16 in, [K,M])", shape, ms, b, K * bc * (2 * N + 8 * M), "byte")
         if not only or "irfft" in only:
             ms, b = timeit(lambda: ops.irfft_raw(xf, tw, N, 1.0, 1.0, 1.0), args.iters)
             report("irfft", shape, ms, b, fft_bytes, "byte")
             ms, b = timeit(lambda: ops.irfft_raw(xf, tw, N, 1.0, 1.0, 1.0, torch.bfloat16), args.iters)
             report("irfft(bf16 out)", shape, ms, b, K * bc * (2 * N + 8 * M), "byte")
+            xfk = xf.permute(1, 0, 2).contiguous()
+            ms, b = timeit(lambda: ops.irfft_raw(xfk, tw, N, 1.0, 1.0, 1.0, torch.bfloat16, kmajor=True), args.iters)
+            report("irfft(bf16 out, [K,M])", shape, ms, b, K * bc * (2 * N + 8 * M), "byte")
+            del xfk
         tabw = ops.legendre_table(grid, K, L, M, True).to(dev)
         c = ops.legendre_fwd_raw(xf, tabw, L)
         leg_flop = 4.0 * T * K * bc
@@ -89,6 +95,14 @@ def main():
             if not only or "legendre_inv" in only:
                 ms, b = timeit(lambda: ops.legendre_inv_raw(c, tabw, K, mode=mode), args.iters)
                 report(f"legendre_inv[{mode}]", shape, ms, b, leg_flop, "flop")
+        if not only or "legendre_fwd" in only:
+            xfk = xf.permute(1, 0, 2).contiguous()
+            ms, b = timeit(lambda: ops.legendre_fwd_raw(xfk, tabw, L, kmajor=True), args.iters)
+            report("legendre_fwd[x3,[K,M]]", shape, ms, b, leg_flop, "flop")
+            del xfk
+        if not only or "legendre_inv" in only:
+            ms, b = timeit(lambda: ops.legendre_inv_raw(c, tabw, K, kmajor=True), args.iters)
+            report("legendre_inv[x3,[K,M]]", shape, ms, b, leg_flop, "flop")
         del x, xb, xf, tabw, c
 
     E, B = args.bc, args.batch
