@@ -336,7 +336,9 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     p.P = P;
     static const int wexp = [] { const char* e = getenv("MK_WGRAD_EXP"); return e ? atoi(e) : 0; }();
     p.exp = wexp;
-    const int MT = 2;   // 128 x 128 blocks (MT = 4: 256-row blocks at one workgroup per CU measured slower)
+    static const int mt_env = [] { const char* e = getenv("MK_WGRAD_MT"); return e ? atoi(e) : 2; }();
+    const int MT = mt_env == 4 ? 4 : 2;   // 128 x 128 blocks; MK_WGRAD_MT=4: 256 x 128 blocks at one workgroup per CU
+    const int slots = MT == 4 ? 32 : 64;  // workgroup slots per XCD
     const int WTO = 64 * MT;
     p.nblk_o = mk::ceil_div(cout, WTO);
     p.nblk_i = mk::ceil_div(cin, WTI);
@@ -354,9 +356,9 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
             long long best_s = 1;
             double best = -1.0;
             for (int w = 1; w <= 4; ++w) {
-                const long long sx = (64LL * w) / nblk1;
+                const long long sx = ((long long)slots * w) / nblk1;
                 if (sx < 1) continue;
-                const double score = (double)(sx * nblk1) / (64.0 * w) - 0.03 * w;
+                const double score = (double)(sx * nblk1) / ((double)slots * w) - 0.03 * w;
                 if (score > best) {
                     best = score;
                     best_s = sx;
@@ -375,7 +377,16 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     const long long grid = ((nslab_tot + 7) / 8) * 8 * p.nblk_o * p.nblk_i;
     MK_REQUIRE(grid < 2147483647LL, "grid too large");
     static const int tk = [] { const char* e = getenv("MK_WGRAD_TK"); return e ? atoi(e) : 64; }();
-    if (tk == 32) {
+    if (MT == 4) {
+        const size_t lds = 2 * (size_t)((WTO + WTI) * (64 * 2 + 16));
+        static const bool once = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_kernel<4, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 128) * 144);
+            return true;
+        }();
+        (void)once;
+        hipLaunchKernelGGL((conv1x1_wgrad_kernel<4, 64>), dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
+    } else if (tk == 32) {
         const size_t lds = 2 * (size_t)((WTO + WTI) * (32 * 2 + 16));
         hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 32>), dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
     } else {
