@@ -142,6 +142,13 @@ struct TransStager {
     }
 };
 
+// Lane -> (row within the wave's 16 rows, 16-byte chunk) for loaders that give a row to four consecutive lanes
+// (128 contiguous bytes of global memory per row).  ds_write_b128 is serviced in groups of 8 consecutive lanes on
+// 32 banks: the two rows of a group must lie 4 rows (4 * 52 = 16 banks mod 32) apart, not 1 (20 banks: the first
+// chunk of the second row lands on the banks of the last chunk of the first -- measured as 33 % LDS conflict cycles
+// in dhconv_dgrad, `profiles/r01_pmc_util.json`).
+__device__ __forceinline__ int quad_row(int lane) { return ((lane >> 3) & 3) + 8 * (lane >> 5) + 4 * ((lane >> 2) & 1); }
+
 // Row-major fp32 A operand, k contiguous: element (r, k) = base[r * ld + k], rows < rows, k < kvalid
 // (kvalid a multiple of 4, rows 16-byte aligned).  Two (row, 8 k) tasks per thread.
 struct RowStager {
@@ -153,7 +160,7 @@ struct RowStager {
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int t = tid + q * XT, row = t >> 2, k = kt * XK + (t & 3) * 8;
+            const int t = tid + q * XT, row = (t >> 6) * 16 + quad_row(t & 63), k = kt * XK + (t & 3) * 8;
             const float* p = base + (long long)row * ld + k;
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -165,7 +172,7 @@ struct RowStager {
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int t = tid + q * XT, row = t >> 2;
+            const int t = tid + q * XT, row = (t >> 6) * 16 + quad_row(t & 63);
             const float v[8] = {r[2 * q].x, r[2 * q].y, r[2 * q].z, r[2 * q].w, r[2 * q + 1].x, r[2 * q + 1].y, r[2 * q + 1].z, r[2 * q + 1].w};
             if (row < rows) split_store8(v, img + row * XPITCH + (t & 3) * 16);
         }
@@ -220,7 +227,7 @@ struct DgradStager {
     typedef float4 Regs[2];
     static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
-        const int i = tid >> 2, o = kt * (XK / 2) + (tid & 3) * 4;
+        const int i = (tid >> 6) * 16 + quad_row(tid & 63), o = kt * (XK / 2) + (tid & 3) * 4;
         const float* p = base + ((long long)i * O + o) * 2;
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -229,7 +236,7 @@ struct DgradStager {
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
-        const int i = tid >> 2, c = tid & 3;
+        const int i = (tid >> 6) * 16 + quad_row(tid & 63), c = tid & 3;
         const float a[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
         const float b[8] = {-r[0].y, r[0].x, -r[0].w, r[0].z, -r[1].y, r[1].x, -r[1].w, r[1].z};
         split_store8(a, img + i * XPITCH + c * 16);
