@@ -20,6 +20,11 @@ class MicroBatchRunner:
     def __init__(self, n):
         self.n = int(n)
         self.streams = [torch.cuda.Stream() for _ in range(self.n)]
+        # parameters are accumulated on the stream they were created on (the calling stream) while their gradients
+        # arrive from the micro-batch streams: intended here, the engine orders the two with events
+        quiet = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if quiet is not None:
+            quiet(False)
         if comm.get_world_size() > 1:
             while comm.num_lanes() < self.n:
                 comm.add_lane()
