@@ -2,6 +2,7 @@
 // viewed as [C][P = H*W] (the pointwise stack between the spectral ops).
 //
 // mk_conv1x1_wgrad:  gW[o][i] += sum_p gY[o][p] * X[i][p]    (contraction over the ~1e5..1e6 pixels)
+// mk_conv1x1_fwd:    Y[m][p] = sum_k A[m][k] * X[k][p] (+ addend)   (forward / data gradient; further down)
 //
 // Both operands are contiguous along the contraction index p, which is exactly the fragment shape of
 // v_mfma_f32_32x32x16_bf16 (lane (r, h) holds 8 consecutive k of row r): tiles are staged with plain

@@ -15,8 +15,10 @@
 // k-step is prefetched into registers while the MFMAs run and converted / written after a barrier
 // (53.5 KB -> 3 workgroups per CU cover each other's staging phases).  Measured alternatives: a register ring
 // 2-4 k-steps deep for the streamed operand (2 workgroups per CU) and a 512-thread 256 x 128 tile with two
-// LDS stages (1 per CU) were both slower -- the load path runs at its throughput for this HBM / L2 mix
-// (~43 GB/s per CU) and only occupancy overlaps it with the MFMA phase.
+// LDS stages (1 per CU) were both slower.  Alone, the load stream of the full-resolution analysis takes 0.22 ms
+// (~43 GB/s per CU for its HBM / L2 mix) and the MFMA phase 0.19 ms; the two barriers per k-step serialise them inside
+// a workgroup and the three workgroups per CU recover about two thirds of the overlap (0.31 ms).  Shrinking the panel
+// bytes by a third (fp32 tiles, MK_X3_TABLE=f32) moves the total by 2 %: the limit is that serialisation, not bytes.
 //
 // Operands whose contraction index is the slow memory axis (k-major rows, n contiguous) are transposed
 // in the staging pass: a thread loads 8 consecutive k of two adjacent columns (float2 per row, 512 B per
