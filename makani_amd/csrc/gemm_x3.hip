@@ -18,7 +18,9 @@
 // LDS stages (1 per CU) were both slower.  Alone, the load stream of the full-resolution analysis takes 0.22 ms
 // (~43 GB/s per CU for its HBM / L2 mix) and the MFMA phase 0.19 ms; the two barriers per k-step serialise them inside
 // a workgroup and the three workgroups per CU recover about two thirds of the overlap (0.31 ms).  Shrinking the panel
-// bytes by a third (fp32 tiles, MK_X3_TABLE=f32) moves the total by 2 %: the limit is that serialisation, not bytes.
+// bytes by a third (fp32 tiles, MK_X3_TABLE=f32) moves the total by 2 %, and a half-step pipeline (refill k 0..15 of
+// the stage while the MFMAs read k 16..31, barriers that wait on nothing) left Legendre unchanged and cost dhconv
+// 5-10 %: neither bytes nor the barrier placement is the limit.
 //
 // Operands whose contraction index is the slow memory axis (k-major rows, n contiguous) are transposed
 // in the staging pass: a thread loads 8 consecutive k of two adjacent columns (float2 per row, 512 B per
