@@ -378,7 +378,9 @@ template <int S>
 int launch_rfft_split(const void* x, int x_dtype, float* xf, const float* tw, int bc, int nlat, int mmax, float s0,
                       float sm, float sh, hipStream_t st) {
     constexpr int G = SNSUB / S;
-    // one workgroup per tile (persistence costs it 70 VGPRs); rounded up to whole XCD pair groups
+    // one workgroup per tile, rounded up to whole XCD pair groups.  Persistence was measured twice: with a prefetch of
+    // the next rows it costs 70 VGPRs; as a plain loop over tiles at 2-4 workgroups per CU it is 13-33 % slower than this
+    // launch-per-tile form although wave launches alone account for 0.14 of the 0.59 ms (MK_FFT_EXP=15).
     const dim3 grid((unsigned)((mk::ceil_div(bc, G) * nlat + 15) / 16 * 16));
     const size_t lds = sizeof(float2) * SLDS_F2;
     if (x_dtype == 0)
