@@ -34,9 +34,16 @@ class _PointwiseConv(torch.autograd.Function):
         ctx.save_for_backward(x3, w)
         ctx.has_addend = addend is not None
         if addend is not None:
+            # y = addend + W x accumulated IN PLACE into the addend's storage: an out-of-place addmm first copies the
+            # addend into the result (one D2D copy of the whole activation per block, 0.5 ms per step).  The addend is
+            # the block's norm1 output, which no backward needs (the norm keeps its input and statistics, this node
+            # returns gy for it); should anyone have saved it, autograd's version check fails loudly in backward.
+            out = addend.detach()
             if x3.shape[0] == 1:
-                return torch.addmm(addend[0], w, x3[0]).unsqueeze(0)
-            return torch.baddbmm(addend, w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
+                torch.addmm(out[0], w, x3[0], out=out[0])
+            else:
+                torch.baddbmm(out, w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3, out=out)
+            return out
         if x3.shape[0] == 1:
             return torch.mm(w, x3[0]).unsqueeze(0)
         return torch.bmm(w.unsqueeze(0).expand(x3.shape[0], -1, -1), x3)
