@@ -288,6 +288,7 @@ def main():
     tar = torch.randn(B, 73, lat_loc, 1440, device=dev)
     _, wq = ops.quadrature("equiangular", 721)
     wq = torch.from_numpy(wq / wq.sum() / 1440.0).float()[lat_off:lat_off + lat_loc].to(dev).view(1, 1, -1, 1)
+    wq_row = wq.view(-1).contiguous()           # quadrature weight per local latitude row (fused loss kernel)
 
     timer = KernelTimer()
     if not args.no_kernel_timing:
@@ -306,7 +307,7 @@ def main():
         def mb_loss(j):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 pred = net(inp[j * mb:(j + 1) * mb])
-            return (((pred.float() - tar[j * mb:(j + 1) * mb]) ** 2) * wq).sum() / (B * 73)
+            return ops.weighted_mse(pred, tar[j * mb:(j + 1) * mb], wq_row, 1.0 / (B * 73))
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -319,7 +320,7 @@ def main():
             return loss
         with torch.autocast("cuda", dtype=torch.bfloat16):
             pred = net(inp)
-        loss = (((pred.float() - tar) ** 2) * wq).sum() / (B * 73)
+        loss = ops.weighted_mse(pred, tar, wq_row, 1.0 / (B * 73))
         loss.backward()
         mappings.reduce_shared_gradients(net)
         opt.step()
@@ -356,7 +357,7 @@ def main():
         with torch.cuda.graph(graph):
             with torch.autocast("cuda", dtype=torch.bfloat16):
                 pred = net(inp)
-            static_loss = (((pred.float() - tar) ** 2) * wq).sum() / (B * 73)
+            static_loss = ops.weighted_mse(pred, tar, wq_row, 1.0 / (B * 73))
             static_loss.backward()
 
         def timed_step():

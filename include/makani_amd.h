@@ -203,6 +203,15 @@ int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const 
                        int fuse_gelu, int phase, void* stream);
 
 /* ---- 1x1 convolution weight gradient (bf16 MFMA) ------------------------------------------ */
+/* Latitude-weighted squared error of the training harness (latitude weights as in
+ * makani/utils/losses.py:149-271):  loss = scale * sum_{r,w} wrow[r % H] * (pred[r][w] - tar[r][w])^2 over rows
+ * r = (b, c, h) of W points (W % 8 == 0); pred fp32 (dtype 0) or bf16 (1), tar fp32, loss one double (zeroed here).
+ * Backward: gpred = 2 * scale * gloss[0] * wrow[r % H] * (pred - tar) in pred's dtype. */
+int mk_wmse_fwd(const void* pred, int dtype, const float* tar, const float* wrow, double* loss, long long rows,
+                int H, int W, float scale, void* stream);
+int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const float* wrow, const float* gloss, void* gpred,
+                long long rows, int H, int W, float scale, void* stream);
+
 /* gw[o][i] += sum over (b, p) of gy[b][o][p] * x[b][i][p]; gy, x bf16 [B][C][P] (P multiple of 8), gw fp32
  * [cout][cin] accumulated with atomics (caller zeroes it).  The weight gradient of nn.Conv2d(cin, cout, 1)
  * in MLP / EncoderDecoder / skip connections (layers.py:95-128,158-183; sfnonet.py:207,463). */

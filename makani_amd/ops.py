@@ -578,6 +578,41 @@ class _InstanceNorm(torch.autograd.Function):
         return gx, gw, gb, None, None, None, None
 
 
+class _WeightedMSE(torch.autograd.Function):
+    """scale * sum wrow[h] (pred - tar)^2 over [B, C, H, W]; one streaming pass each way (mk_wmse_*)."""
+
+    @staticmethod
+    def forward(ctx, pred, tar, wrow, scale):
+        _need_cuda(pred, tar, wrow)
+        B, C, H, W = pred.shape
+        loss = torch.empty(1, dtype=torch.float64, device=pred.device)
+        _lib.check(_lib.load().mk_wmse_fwd(pred.data_ptr(), _pw_dtype(pred), tar.data_ptr(), wrow.data_ptr(), loss.data_ptr(),
+                                           B * C * H, H, W, float(scale), _stream()), "mk_wmse_fwd")
+        ctx.save_for_backward(pred, tar, wrow)
+        ctx.scale = float(scale)
+        return loss.float().squeeze(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, tar, wrow = ctx.saved_tensors
+        B, C, H, W = pred.shape
+        gp = torch.empty_like(pred)
+        g32 = g.detach().float().reshape(1).contiguous()
+        _lib.check(_lib.load().mk_wmse_bwd(pred.data_ptr(), _pw_dtype(pred), tar.data_ptr(), wrow.data_ptr(), g32.data_ptr(),
+                                           gp.data_ptr(), B * C * H, H, W, ctx.scale, _stream()), "mk_wmse_bwd")
+        return gp, None, None, None
+
+
+def weighted_mse(pred, tar, wrow, scale=1.0):
+    """``scale * (((pred - tar) ** 2) * wrow[None, None, :, None]).sum()`` for pred [B, C, H, W] (fp32 / bf16, contiguous),
+    tar fp32 of the same shape, wrow fp32 [H]; gradient w.r.t. pred only."""
+    if not (pred.is_cuda and pred.is_contiguous() and tar.is_contiguous() and tar.dtype == torch.float32
+            and pred.dtype in (torch.float32, torch.bfloat16) and pred.shape[-1] % 8 == 0):
+        w = wrow.view(1, 1, -1, 1)
+        return scale * (((pred.float() - tar) ** 2) * w).sum()
+    return _WeightedMSE.apply(pred, tar, wrow.float().contiguous(), scale)
+
+
 def bias_gelu(x, bias):
     return _BiasGelu.apply(x, bias)
 

@@ -435,3 +435,22 @@ def test_legendre_latitude_major_layout(dev, grid, nlat, lmax, mmax, bc):
     y0 = ops.legendre_inv_raw(cm, tab, nlat, mode="bf16x3")
     y1 = ops.legendre_inv_raw(cm, tab, nlat, kmajor=True)
     assert tuple(y1.shape) == (nlat, mmax, bc) and torch.equal(y0.permute(1, 0, 2), y1)
+
+
+# --------------------------------------------------------------------------- fused latitude-weighted MSE (bench loss)
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_weighted_mse(dev, dtype):
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 2, 5, 19, 64
+    pred = torch.randn(B, C, H, W, generator=g).to(dtype).to(dev).requires_grad_(True)
+    tar = torch.randn(B, C, H, W, generator=g).to(dev)
+    w = torch.rand(H, generator=g).to(dev)
+    loss = ops.weighted_mse(pred, tar, w, 0.25)
+    (gp,) = torch.autograd.grad(loss, pred)
+    pr = pred.detach().double().requires_grad_(True)
+    want = 0.25 * (((pr - tar.double()) ** 2) * w.double().view(1, 1, -1, 1)).sum()
+    (gw,) = torch.autograd.grad(want, pr)
+    assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item())
+    tol = 1e-6 if dtype == torch.float32 else 4e-3      # the gradient is rounded to pred's dtype
+    assert rel(gp.float().cpu().numpy(), gw.cpu().numpy()) < tol
