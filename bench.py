@@ -247,7 +247,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--graph", action="store_true",
@@ -372,6 +372,11 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     timer.enabled = not args.no_kernel_timing and not args.graph
+    # Python's cyclic garbage collector is kept out of the timed region (a generation-2 pass over the process's objects
+    # stalls one step by 70-90 ms around step 10 of a fresh process: tools/step_times.py); collected before and after.
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = timed_step()
@@ -380,6 +385,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timer.enabled = False
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -412,7 +418,7 @@ def main():
                        "global_batch": B, "parallelism": f"h{hsize}", "spectral_dtype": "f32 (GEMMs as 6 bf16 MFMA products of exact 3-way operand splits)"
                        if spectral_mode == "bf16x3" else "f32",
                        "step_launch": "hipGraph replay" if args.graph else "eager",
-                       "micro_batches": nmb},
+                       "micro_batches": nmb, "python_gc": "disabled in the timed region"},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
             "kernel_timing": ("HIP events: all kernels over the last %d warm-up step(s), the roofline kernel over the timed region"
                               % n_probe) if n_probe else ("HIP events over an eager pre-pass" if args.graph else
