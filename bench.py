@@ -329,6 +329,18 @@ def main():
     # Kernel table: every hand-written spectral / wgrad launch is bracketed with HIP events during the LAST warm-up
     # steps (~500 events per step cost 3 % of the step time, so they are kept out of the timed region); the timed
     # region then records only the launches of the dominant kernel -- the `roofline` figures come from there.
+    if runner is not None:
+        # one guarded step: an error in the two-stream / two-communicator path is deterministic (every rank runs the same
+        # program), so all ranks fall back to the single-stream step together instead of losing the run
+        try:
+            step()
+            torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            print(f"[bench] micro-batched step failed ({type(e).__name__}: {e}); continuing on one stream", file=sys.stderr,
+                  flush=True)
+            runner, nmb = None, 1
+            opt.zero_grad(set_to_none=True)
+
     timed_step = step
     pre_kernels = None
     n_probe = 0 if (args.no_kernel_timing or args.graph) else min(args.warmup, 2)
