@@ -94,8 +94,11 @@ class KernelTimer:
             return 8.0 * out.shape[1] * out.shape[2] * tri_pairs(lloc, mloc, l_off, m_off) * batch, "flop"
 
         def conv_wgrad_work(out, gy, x3):
+            # arithmetic intensity O*I/(O+I) <= 256 flop/byte at the production shapes, below the bf16 ridge point
+            # (2517 TFLOP/s / 8 TB/s = 315): HBM is the roof -- both bf16 operands read once, the fp32 gradient written
             b, o, p = gy.shape
-            return 2.0 * o * x3.shape[1] * p * b, "flop_bf16"
+            i = x3.shape[1]
+            return float(2 * (o + i) * p * b + 4 * o * i), "byte"
 
         def rfft_work(out, x, tw, mmax, *s, **kw):
             bc, k, n = x.shape
