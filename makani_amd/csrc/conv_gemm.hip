@@ -62,7 +62,7 @@ __device__ __forceinline__ void wg_store(char* lds, const uint4 (&r)[NV], int ti
     }
 }
 
-template <int MT, int WTK>   // 32-row o-tiles per wave: workgroup tile (64 * MT) x 128; k-step in pixels
+template <int MT, int WTK, int RD = 1>   // 32-row o-tiles per wave: workgroup tile (64 * MT) x 128; k-step (pixels); ring depth
 __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
     constexpr int WVPR = WTK / 8, WPITCH = WTK * 2 + 16, WTILE_BYTES = WTI * WPITCH;
     constexpr int WTO = 64 * MT, ATILE = WTO * WPITCH, BUF = ATILE + WTILE_BYTES, NVA = WTO * WVPR / WT, NVB = WTI * WVPR / WT;
@@ -94,43 +94,57 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
 
-    uint4 ra[NVA], rb[NVB];
+    // Register ring RD k-steps deep: one k-step of MFMAs is only 16 x 32 = 512 cycles, far less than a load's flight
+    // time, so the loads of k-step kt + 1 + RD are issued when the registers of k-step kt + 1 have been written to LDS.
+    uint4 ra[RD][NVA], rb[RD][NVB];
     const int nk = (int)((k_end - k_begin + WTK - 1) / WTK);
-    wg_load<NVA, WVPR>(ga, p.P, ov, k_begin, k_end, ra, tid);
-    wg_load<NVB, WVPR>(gb, p.P, iv, k_begin, k_end, rb, tid);
-    wg_store<NVA, WVPR>(lds, ra, tid);
-    wg_store<NVB, WVPR>(lds + ATILE, rb, tid);
+    wg_load<NVA, WVPR>(ga, p.P, ov, k_begin, k_end, ra[0], tid);
+    wg_load<NVB, WVPR>(gb, p.P, iv, k_begin, k_end, rb[0], tid);
+    wg_store<NVA, WVPR>(lds, ra[0], tid);
+    wg_store<NVB, WVPR>(lds + ATILE, rb[0], tid);
+#pragma unroll
+    for (int d = 0; d < RD; ++d)
+        if (d + 1 < nk) {
+            const long long k0 = k_begin + (long long)(d + 1) * WTK;
+            wg_load<NVA, WVPR>(ga, p.P, ov, k0, k_end, ra[d], tid);
+            wg_load<NVB, WVPR>(gb, p.P, iv, k0, k_end, rb[d], tid);
+        }
     __syncthreads();
     const int fr = lane & 31, fh = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) {
-            const long long k0 = k_begin + (long long)(kt + 1) * WTK;
-            wg_load<NVA, WVPR>(ga, p.P, ov, k0, k_end, ra, tid);
-            wg_load<NVB, WVPR>(gb, p.P, iv, k0, k_end, rb, tid);
-        }
-        const char* As = lds + cur * BUF;
-        const char* Bs = As + ATILE;
+    for (int ktb = 0; ktb < nk; ktb += RD) {
 #pragma unroll
-        for (int ks = 0; ks < WTK / 16; ++ks) {
-            bf16x8 af[MT], bf[2];
+        for (int d = 0; d < RD; ++d) {      // ring slot d holds k-step kt + 1
+            const int kt = ktb + d;
+            if (kt >= nk) break;
+            const int cur = kt & 1;
+            const char* As = lds + cur * BUF;
+            const char* Bs = As + ATILE;
 #pragma unroll
-            for (int a = 0; a < MT; ++a)
-                af[a] = *reinterpret_cast<const bf16x8*>(As + (wr * 32 * MT + a * 32 + fr) * WPITCH + ks * 32 + fh * 16);
+            for (int ks = 0; ks < WTK / 16; ++ks) {
+                bf16x8 af[MT], bf[2];
 #pragma unroll
-            for (int c = 0; c < 2; ++c)
-                bf[c] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + c * 32 + fr) * WPITCH + ks * 32 + fh * 16);
-#pragma unroll
-            for (int a = 0; a < MT; ++a)
+                for (int a = 0; a < MT; ++a)
+                    af[a] = *reinterpret_cast<const bf16x8*>(As + (wr * 32 * MT + a * 32 + fr) * WPITCH + ks * 32 + fh * 16);
 #pragma unroll
                 for (int c = 0; c < 2; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
+                    bf[c] = *reinterpret_cast<const bf16x8*>(Bs + (wc * 64 + c * 32 + fr) * WPITCH + ks * 32 + fh * 16);
+#pragma unroll
+                for (int a = 0; a < MT; ++a)
+#pragma unroll
+                    for (int c = 0; c < 2; ++c)
+                        acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
+            }
+            if (kt + 1 < nk) {
+                wg_store<NVA, WVPR>(lds + (cur ^ 1) * BUF, ra[d], tid);
+                wg_store<NVB, WVPR>(lds + (cur ^ 1) * BUF + ATILE, rb[d], tid);
+                if (kt + 1 + RD < nk) {
+                    const long long k0 = k_begin + (long long)(kt + 1 + RD) * WTK;
+                    wg_load<NVA, WVPR>(ga, p.P, ov, k0, k_end, ra[d], tid);
+                    wg_load<NVB, WVPR>(gb, p.P, iv, k0, k_end, rb[d], tid);
+                }
+            }
+            __syncthreads();
         }
-        if (kt + 1 < nk) {
-            wg_store<NVA, WVPR>(lds + (cur ^ 1) * BUF, ra, tid);
-            wg_store<NVB, WVPR>(lds + (cur ^ 1) * BUF + ATILE, rb, tid);
-        }
-        __syncthreads();
     }
     // C/D map: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5); rows = o, cols = i
 #pragma unroll
@@ -148,6 +162,120 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
 }
 
 
+
+// ---------------------------------------------------------------------------
+// Large-block weight gradient: 512 threads (8 waves as WR x WC), a (WR*RT*32) x (WC*CT*32) block of gW per workgroup,
+// one workgroup per CU.  All GEMM-shaped kernels of this library stall at the same ~10 TB/s of L2 -> CU traffic
+// (~43 GB/s per CU); the 128 x 128 block moves 32 bytes per thousand multiply-adds through that path, 256 x 192 moves 18.
+// Used where the block divides the matrix: 768 x 384 as 256 x 192 (4 x 2 waves of 64 x 96), 384 x 768 as 192 x 256.
+// ---------------------------------------------------------------------------
+constexpr int WT8 = 512;
+
+template <int NV>
+__device__ __forceinline__ void wg8_load(const __hip_bfloat16* base, long long ld, int rows_valid, long long k0,
+                                         long long kend, uint4 (&r)[NV], int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * WT8, row = v >> 3, c = v & 7;
+        const long long k = k0 + c * 8;
+        r[i] = make_uint4(0u, 0u, 0u, 0u);
+        if (row < rows_valid && k < kend) r[i] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
+    }
+}
+template <int NV>
+__device__ __forceinline__ void wg8_store(char* lds, const uint4 (&r)[NV], int tid) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int v = tid + i * WT8, row = v >> 3, c = v & 7;
+        *reinterpret_cast<uint4*>(lds + row * 144 + c * 16) = r[i];
+    }
+}
+
+template <int WR, int WC, int RT, int CT>
+__global__ __launch_bounds__(WT8) void conv1x1_wgrad_big_kernel(WgradParams p) {
+    constexpr int TMB = WR * RT * 32, TNB = WC * CT * 32, PITCH = 144;
+    constexpr int ATILE = TMB * PITCH, BTILE = TNB * PITCH, BUF = ATILE + BTILE;
+    constexpr int NVA = TMB * 8 / WT8, NVB = TNB * 8 / WT8;
+    static_assert(WR * WC == 8 && TMB * 8 % WT8 == 0 && TNB * 8 % WT8 == 0, "tile / thread mapping");
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WC, wc = wave % WC;
+    const int nblk = p.nblk_o * p.nblk_i;
+    const long long bid = blockIdx.x;
+    const int xcd = (int)(bid & 7);
+    const long long seq = bid >> 3;
+    const long long slab_lin = (seq / nblk) * 8 + xcd;
+    const int blk = (int)(seq % nblk);
+    const long long nslab_tot = (long long)p.nslab * p.B;
+    if (slab_lin >= nslab_tot) return;
+    const int b = (int)(slab_lin / p.nslab);
+    const long long k_begin = (slab_lin % p.nslab) * p.slab;
+    const long long k_end = (k_begin + p.slab < p.P) ? k_begin + p.slab : p.P;
+    const int o0 = (blk / p.nblk_i) * TMB, i0 = (blk % p.nblk_i) * TNB;
+    const __hip_bfloat16* ga = p.gy + ((long long)b * p.O + o0) * p.P;
+    const __hip_bfloat16* gb = p.x + ((long long)b * p.I + i0) * p.P;
+    const int ov = p.O - o0, iv = p.I - i0;
+
+    f32x16 acc[RT][CT];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+
+    uint4 ra[NVA], rb[NVB];
+    const int nk = (int)((k_end - k_begin + 63) / 64);
+    wg8_load<NVA>(ga, p.P, ov, k_begin, k_end, ra, tid);
+    wg8_load<NVB>(gb, p.P, iv, k_begin, k_end, rb, tid);
+    wg8_store<NVA>(lds, ra, tid);
+    wg8_store<NVB>(lds + ATILE, rb, tid);
+    __syncthreads();
+    const int fr = lane & 31, fh = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) {
+            const long long k0 = k_begin + (long long)(kt + 1) * 64;
+            wg8_load<NVA>(ga, p.P, ov, k0, k_end, ra, tid);
+            wg8_load<NVB>(gb, p.P, iv, k0, k_end, rb, tid);
+        }
+        const char* As = lds + cur * BUF;
+        const char* Bs = As + ATILE;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 af[RT], bf[CT];
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+                af[a] = *reinterpret_cast<const bf16x8*>(As + ((wr * RT + a) * 32 + fr) * PITCH + ks * 32 + fh * 16);
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+                bf[c] = *reinterpret_cast<const bf16x8*>(Bs + ((wc * CT + c) * 32 + fr) * PITCH + ks * 32 + fh * 16);
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+#pragma unroll
+                for (int c = 0; c < CT; ++c)
+                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
+        }
+        if (kt + 1 < nk) {
+            wg8_store<NVA>(lds + (cur ^ 1) * BUF, ra, tid);
+            wg8_store<NVB>(lds + (cur ^ 1) * BUF + ATILE, rb, tid);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+            const int col = i0 + (wc * CT + c) * 32 + fr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = o0 + (wr * RT + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (row < p.O && col < p.I && (!(p.exp & 1) || acc[a][c][r] == 12345.678f))
+                    atomicAdd(&p.gw[(long long)row * p.I + col], acc[a][c][r]);
+            }
+        }
+}
 
 // ---------------------------------------------------------------------------
 // mk_conv1x1_fwd:  Y[b][m][p] = sum_k A[m][k] * X[b][k][p] (+ addend[b][m][p])
@@ -337,6 +465,55 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     p.P = P;
     static const int wexp = [] { const char* e = getenv("MK_WGRAD_EXP"); return e ? atoi(e) : 0; }();
     p.exp = wexp;
+    // Large blocks where they divide the matrix exactly and the contraction is long: measured 10 % faster at 721 x 1440
+    // pixels (0.96 vs 1.07 ms for 768 x 384), 35 % slower at 240 x 480 where one workgroup per CU cannot hide its own
+    // load latency over 45 k-steps.  MK_WGRAD_BIG=0 disables, =2 forces.
+    static const int big_env = [] { const char* e = getenv("MK_WGRAD_BIG"); return e ? atoi(e) : 1; }();
+    const bool big_ok = big_env == 2 || (big_env == 1 && P * batch >= 400000);
+    const bool big_a = big_ok && cout % 256 == 0 && cin % 192 == 0;    // 256 x 192 blocks
+    const bool big_b = big_ok && !big_a && cout % 192 == 0 && cin % 256 == 0;    // 192 x 256 blocks
+    if (big_a || big_b) {
+        const int TMB = big_a ? 256 : 192, TNB = big_a ? 192 : 256;
+        p.nblk_o = cout / TMB;
+        p.nblk_i = cin / TNB;
+        const long long nblk1 = (long long)p.nblk_o * p.nblk_i;
+        long long best_s = 1;
+        double best = -1.0;
+        for (int w = 1; w <= 4; ++w) {                 // 32 workgroup slots per XCD (one 512-thread workgroup per CU)
+            const long long sx = (32LL * w) / nblk1;
+            if (sx < 1) continue;
+            const double score = (double)(sx * nblk1) / (32.0 * w) - 0.03 * w;
+            if (score > best) {
+                best = score;
+                best_s = sx;
+            }
+        }
+        long long want = (8 * best_s + batch - 1) / batch;
+        if (want < 1) want = 1;
+        long long slab = (P + want - 1) / want;
+        slab = (slab + 63) / 64 * 64;
+        if (slab < 512) slab = 512;
+        p.slab = (int)slab;
+        p.nslab = (int)((P + p.slab - 1) / p.slab);
+        const long long nslab_tot = (long long)p.nslab * batch;
+        const long long grid = ((nslab_tot + 7) / 8) * 8 * nblk1;
+        MK_REQUIRE(grid < 2147483647LL, "grid too large");
+        const size_t lds = 2 * (size_t)(256 + 192) * 144;
+        static const bool once = [] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_big_kernel<4, 2, 2, 3>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * 144);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_big_kernel<2, 4, 3, 2>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (256 + 192) * 144);
+            return true;
+        }();
+        (void)once;
+        if (big_a)
+            hipLaunchKernelGGL((conv1x1_wgrad_big_kernel<4, 2, 2, 3>), dim3((unsigned)grid), dim3(WT8), lds, (hipStream_t)stream, p);
+        else
+            hipLaunchKernelGGL((conv1x1_wgrad_big_kernel<2, 4, 3, 2>), dim3((unsigned)grid), dim3(WT8), lds, (hipStream_t)stream, p);
+        MK_LAUNCH_CHECK();
+        return 0;
+    }
     static const int mt_env = [] { const char* e = getenv("MK_WGRAD_MT"); return e ? atoi(e) : 2; }();
     const int MT = mt_env == 4 ? 4 : 2;   // 128 x 128 blocks; MK_WGRAD_MT=4: 256 x 128 blocks at one workgroup per CU
     const int slots = MT == 4 ? 32 : 64;  // workgroup slots per XCD
@@ -392,7 +569,14 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
         hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 32>), dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
     } else {
         const size_t lds = 2 * (size_t)((WTO + WTI) * (64 * 2 + 16));
-        hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64>), dim3((unsigned)grid), dim3(WT), lds, (hipStream_t)stream, p);
+        static const int rd = [] { const char* e = getenv("MK_WGRAD_RING"); return e ? atoi(e) : 1; }();
+        const dim3 g((unsigned)grid), b(WT);
+        switch (rd) {
+            case 2: hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64, 2>), g, b, lds, (hipStream_t)stream, p); break;
+            case 3: hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64, 3>), g, b, lds, (hipStream_t)stream, p); break;
+            case 4: hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64, 4>), g, b, lds, (hipStream_t)stream, p); break;
+            default: hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64, 1>), g, b, lds, (hipStream_t)stream, p); break;
+        }
     }
     MK_LAUNCH_CHECK();
     return 0;

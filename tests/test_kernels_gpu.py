@@ -350,7 +350,8 @@ def test_instance_norm(dev, B, C, H, W, dtype, fuse):
 
 
 @pytest.mark.parametrize("B,O,I,P", [(1, 128, 128, 4096), (2, 73, 384, 33 * 64), (1, 768, 384, 240 * 480), (3, 5, 7, 24),
-                                      (1, 384, 73, 16384 + 8)])
+                                      (1, 384, 73, 16384 + 8),
+                                      (1, 768, 384, 400008), (2, 384, 768, 200008)])   # large-block kernels (256x192 / 192x256)
 def test_conv1x1_wgrad(dev, B, O, I, P):
     from makani_amd import _lib, ops
     g = torch.Generator().manual_seed(9)
