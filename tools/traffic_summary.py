@@ -21,7 +21,7 @@ NAMES = [("irfft", "irfft_split_kernel"), ("irfft", "irfft_kernel"), ("rfft", "r
          ("dhconv_wgrad", "dhconv_wgrad_x3_kernel"),
          ("legendre_fwd", "legendre_fwd_kernel"), ("legendre_inv", "legendre_inv_kernel"),
          ("dhconv_fwd", "dhconv_fwd_kernel"), ("dhconv_dgrad", "dhconv_dgrad_kernel"),
-         ("dhconv_wgrad", "dhconv_wgrad_kernel"), ("conv1x1_wgrad", "conv1x1_wgrad_kernel"), ("bias_gelu_fwd", "bias_gelu_fwd_kernel"),
+         ("dhconv_wgrad", "dhconv_wgrad_kernel"), ("conv1x1_wgrad", "conv1x1_wgrad_kernel"), ("conv1x1_wgrad", "conv1x1_wgrad_big_kernel"), ("bias_gelu_fwd", "bias_gelu_fwd_kernel"),
          ("bias_gelu_bwd", "bias_gelu_bwd_kernel"), ("instnorm", "instnorm_"), ("instnorm", "rowsum2_kernel")]
 
 
