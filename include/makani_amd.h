@@ -129,6 +129,15 @@ int mk_legendre_fwd_x3_ex(const float* xf, const void* tab_x3, float* c, int bc,
 int mk_legendre_inv_x3_ex(const float* c, const void* tab_x3, float* xf, int bc, int nlat, int lmax,
                           int mmax_loc, int m_off, int mmax_glob, int xf_layout, void* stream);
 
+/* Peer-major Fourier rows for the distributed transform: bc = batch * chans rows, the channels cut into blocks of
+ * chans_per_peer (a multiple of 24), xf = [chans / chans_per_peer][nlat][mmax][batch][chans_per_peer] -- exactly the send
+ * (analysis) / receive (synthesis) buffer of the channel <-> latitude all-to-all, so that side of the transpose needs no
+ * pack / concatenate copy either.  Production lengths only (nlon 480 / 1440, mmax <= 241). */
+int mk_rfft_pm(const void* x, int x_dtype, float* xf, const float* twiddles, int bc, int nlat, int nlon, int mmax,
+               float scale0, float scale_m, float scale_h, int chans, int chans_per_peer, void* stream);
+int mk_irfft_pm(const float* xf, void* x, int x_dtype, const float* twiddles, int bc, int nlat, int nlon, int mmax,
+                float scale0, float scale_m, float scale_h, int chans, int chans_per_peer, void* stream);
+
 /* ---- spectral filter contraction (K5) ---------------------------------- */
 /* y[l][m][b][o] = sum_i x[l][m][b][i] * w[l][i][o]  (complex), for global m <= l.
  * Replaces _contract_dhconv `einsum("bixy,iox->boxy")` (contractions.py:130-136,

@@ -22,10 +22,32 @@ namespace {
 
 // Layout of the Fourier rows xf: element (m, k, bc) at ((m * sm + k * sk) * BC + bc) complex numbers.
 //   [M][K][BC] (default): sm = K, sk = 1.     [K][M][BC] (latitude major, distributed SHT): sm = 1, sk = M.
+// Peer-major (Cp > 0, split kernels only): the channels c = bc % C are cut into blocks of Cp (one per rank of the
+// latitude group) and the block index is the OUTERMOST axis, [P][K][M][B][Cp]: element at
+//   p * pstride + ((m * sm + k * sk) * (B * Cp) + b * Cp + c % Cp),  p = c / Cp, b = bc / C, sm = 1, sk = M
+// -- the send / receive buffer of the channel <-> latitude all-to-all as it is, no pack or concatenate copy.
 struct XfLayout {
     int sm, sk;
+    int C, Cp, Bn;        // Cp = 0: plain layouts
+    long long pstride;    // K * M * Bn * Cp
 };
-static thread_local XfLayout g_xl = {0, 0};   // set by the C entry points before they launch
+static thread_local XfLayout g_xl = {0, 0, 0, 0, 0, 0};   // set by the C entry points before they launch
+
+// per-tile channel addressing: all G rows of a split-kernel tile lie in one (batch item, channel block) when Cp % G == 0
+struct XfChan {
+    size_t pbase;
+    int bcx0, BCx;
+};
+__device__ __forceinline__ XfChan xf_chan(const XfLayout& xl, int bc0, int BC) {
+    XfChan c{0, bc0, BC};
+    if (xl.Cp) {
+        const int b = bc0 / xl.C, ch = bc0 - b * xl.C, pp = ch / xl.Cp;
+        c.pbase = (size_t)pp * (size_t)xl.pstride;
+        c.bcx0 = b * xl.Cp + (ch - pp * xl.Cp);
+        c.BCx = xl.Bn * xl.Cp;
+    }
+    return c;
+}
 
 
 // ---------------------------------------------------------------------------
@@ -474,7 +496,7 @@ extern "C" int mk_rfft(const void* x, int x_dtype, float* xf, const float* twidd
 extern "C" int mk_rfft_ex(const void* x, int x_dtype, float* xf, const float* twiddles, int bc, int nlat, int nlon,
                           int mmax, float scale0, float scale_m, float scale_h, int xf_layout, void* stream) {
     MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
-    g_xl = xf_layout ? XfLayout{1, mmax} : XfLayout{nlat, 1};
+    g_xl = xf_layout ? XfLayout{1, mmax, 0, 0, 0, 0} : XfLayout{nlat, 1, 0, 0, 0, 0};
     MK_REQUIRE(x && xf && twiddles, "null pointer");
     MK_REQUIRE(bc > 0 && nlat > 0 && nlon >= 2 && nlon % 2 == 0, "bad sizes (nlon must be even)");
     MK_REQUIRE(mmax >= 1 && mmax <= nlon / 2 + 1, "mmax out of range");
@@ -519,7 +541,7 @@ extern "C" int mk_irfft(const float* xf, void* xout, int x_dtype, const float* t
 extern "C" int mk_irfft_ex(const float* xf, void* xout, int x_dtype, const float* twiddles, int bc, int nlat, int nlon,
                            int mmax, float scale0, float scale_m, float scale_h, int xf_layout, void* stream) {
     MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
-    g_xl = xf_layout ? XfLayout{1, mmax} : XfLayout{nlat, 1};
+    g_xl = xf_layout ? XfLayout{1, mmax, 0, 0, 0, 0} : XfLayout{nlat, 1, 0, 0, 0, 0};
     float* x = (float*)xout;
     MK_REQUIRE(x_dtype == 0 || x_dtype == 1, "x_dtype must be 0 (fp32) or 1 (bf16)");
     MK_REQUIRE(x_dtype == 0 || (!fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440)),
@@ -550,6 +572,44 @@ extern "C" int mk_irfft_ex(const float* xf, void* xout, int x_dtype, const float
                                (const float2*)twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, g_xl);
         }
     }
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+// Peer-major Fourier rows (see XfLayout): bc = batch * chans rows, channel blocks of chans_per_peer.
+static int fft_pm_setup(int bc, int nlat, int nlon, int mmax, int chans, int chans_per_peer) {
+    MK_REQUIRE(chans > 0 && chans_per_peer > 0 && bc % chans == 0 && chans % chans_per_peer == 0, "bad channel blocking");
+    MK_REQUIRE(chans_per_peer % 24 == 0, "channel blocks must be multiples of 24 (tiles of 8 / 24 rows must not straddle them)");
+    MK_REQUIRE(!fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440), "peer-major rows exist for the split kernels only");
+    const int Bn = bc / chans;
+    g_xl = XfLayout{1, mmax, chans, chans_per_peer, Bn, (long long)nlat * mmax * Bn * chans_per_peer};
+    return 0;
+}
+
+extern "C" int mk_rfft_pm(const void* x, int x_dtype, float* xf, const float* twiddles, int bc, int nlat, int nlon, int mmax,
+                          float scale0, float scale_m, float scale_h, int chans, int chans_per_peer, void* stream) {
+    MK_REQUIRE(x && xf && twiddles, "null pointer");
+    MK_REQUIRE(bc > 0 && nlat > 0 && mmax >= 1, "bad sizes");
+    MK_REQUIRE(x_dtype == 0 || x_dtype == 1, "x_dtype must be 0 (fp32) or 1 (bf16)");
+    if (int e = fft_pm_setup(bc, nlat, nlon, mmax, chans, chans_per_peer)) return e;
+    if (nlon == 480)
+        launch_rfft_split<1>(x, x_dtype, xf, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, (hipStream_t)stream);
+    else
+        launch_rfft_split<3>(x, x_dtype, xf, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, (hipStream_t)stream);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_irfft_pm(const float* xf, void* x, int x_dtype, const float* twiddles, int bc, int nlat, int nlon, int mmax,
+                           float scale0, float scale_m, float scale_h, int chans, int chans_per_peer, void* stream) {
+    MK_REQUIRE(x && xf && twiddles, "null pointer");
+    MK_REQUIRE(bc > 0 && nlat > 0 && mmax >= 1, "bad sizes");
+    MK_REQUIRE(x_dtype == 0 || x_dtype == 1, "x_dtype must be 0 (fp32) or 1 (bf16)");
+    if (int e = fft_pm_setup(bc, nlat, nlon, mmax, chans, chans_per_peer)) return e;
+    if (nlon == 480)
+        launch_irfft_split<1>(xf, x, x_dtype, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, (hipStream_t)stream);
+    else
+        launch_irfft_split<3>(xf, x, x_dtype, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, (hipStream_t)stream);
     MK_LAUNCH_CHECK();
     return 0;
 }

@@ -108,6 +108,7 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     if (tile >= ntile * K) return;
     const int k = tile / ntile;
     const int bc0 = (tile - k * ntile) * G;
+    const XfChan xc = xf_chan(xl, bc0, BC);
 
     float vals[IT][S][E];
 #pragma unroll
@@ -196,11 +197,11 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
         }
         if (mp < M) {
             const float sc = (mp == 0) ? scale0 : scale_m;
-            xf[((size_t)mp * xl.sm + (size_t)k * xl.sk) * BC + bc] = make_float2(sc * acc0.x, sc * acc0.y);
+            xf[xc.pbase + ((size_t)mp * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)] = make_float2(sc * acc0.x, sc * acc0.y);
         }
         if (m1 != mp && m1 < M) {
             const float sc = (m1 == HH) ? scale_h : scale_m;
-            xf[((size_t)m1 * xl.sm + (size_t)k * xl.sk) * BC + bc] = make_float2(sc * acc1.x, sc * acc1.y);
+            xf[xc.pbase + ((size_t)m1 * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)] = make_float2(sc * acc1.x, sc * acc1.y);
         }
     }
 }
@@ -254,6 +255,7 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
     float2 xa[PIT], xb[PIT];
     auto gather = [&](int t, int tl) {      // the 8-byte mode gathers of tile t (in flight while the previous tile computes)
         const int k = t / ntile, bc0 = (t - k * ntile) * G;
+        const XfChan xc = xf_chan(xl, bc0, BC);
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
             const int idx = tl + it * STHREADS;
@@ -262,8 +264,8 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
             xa[it] = make_float2(0.f, 0.f);
             xb[it] = make_float2(0.f, 0.f);
             if (idx < G * NPAIR && bc < BC) {
-                if (jp < M) xa[it] = xf[((size_t)jp * xl.sm + (size_t)k * xl.sk) * BC + bc];
-                if (j1 < M) xb[it] = xf[((size_t)j1 * xl.sm + (size_t)k * xl.sk) * BC + bc];
+                if (jp < M) xa[it] = xf[xc.pbase + ((size_t)jp * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)];
+                if (j1 < M) xb[it] = xf[xc.pbase + ((size_t)j1 * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)];
             }
         }
     };

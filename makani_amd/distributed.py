@@ -96,6 +96,29 @@ class _DistributedTranspose(torch.autograd.Function):
         return gi, None, None, None
 
 
+class _AllToAllFlat(torch.autograd.Function):
+    """all_to_all_single on a flat buffer whose peer chunks already lie back to back (peer-major Fourier rows on one
+    side, the outermost axis on the other): no pack, no concatenate; backward = the reverse exchange."""
+
+    @staticmethod
+    def forward(ctx, x, in_splits, out_splits, group):
+        ctx.cfg = (in_splits, out_splits, group, tuple(x.shape))
+        send = x.contiguous().view(-1)
+        recv = torch.empty(sum(out_splits), dtype=x.dtype, device=x.device)
+        dist.all_to_all_single(torch.view_as_real(recv).view(-1), torch.view_as_real(send).view(-1),
+                               [2 * s for s in out_splits], [2 * s for s in in_splits], group=group)
+        return recv
+
+    @staticmethod
+    def backward(ctx, g):
+        in_splits, out_splits, group, shape = ctx.cfg
+        send = g.contiguous().view(-1)
+        recv = torch.empty(sum(in_splits), dtype=g.dtype, device=g.device)
+        dist.all_to_all_single(torch.view_as_real(recv).view(-1), torch.view_as_real(send).view(-1),
+                               [2 * s for s in in_splits], [2 * s for s in out_splits], group=group)
+        return recv.view(shape), None, None, None
+
+
 class distributed_transpose_polar:
     """``distributed_transpose_polar.apply(x, (dim0, dim1), dim1_split_sizes)`` over the ``h`` group."""
 
@@ -147,9 +170,17 @@ class DistributedRealSHT(_DistSHTBase):
         if self.comm_size_azimuth == 1 and self.comm_size_polar > 1 and ops.SPECTRAL_GEMM == "bf16x3":
             # latitude-major Fourier rows [K, M, B, C]: the latitude all-to-all gathers the OUTERMOST axis, so the
             # received chunks are the Legendre operand as they arrive (no concatenate copy)
-            xf = ops.rfft(x.reshape(B * C, x.shape[2], self.nlon).contiguous(), self.twiddles, self.mmax, True)
-            xf = xf.view(-1, self.mmax, B, C)                                     # [K_loc, M, B, C]
-            xf = distributed_transpose_polar.apply(xf, (3, 0), self.lat_shapes)    # [K, M, B, C_h]
+            h = self.comm_size_polar
+            if C % h == 0 and ops.fft_pm_supported(self.nlon, self.mmax, C, C // h):
+                # peer-major rows [h, K_loc, M, B, C/h] ARE the send buffer; the received latitude chunks are the operand
+                Ch, kl, unit = C // h, x.shape[2], self.mmax * B * (C // h)
+                xf = ops.rfft_pm(x.reshape(B * C, kl, self.nlon).contiguous(), self.twiddles, self.mmax, C, Ch)
+                xf = _AllToAllFlat.apply(xf, [kl * unit] * h, [k * unit for k in self.lat_shapes], comm.get_group("h"))
+                xf = xf.view(self.nlat, self.mmax, B, Ch)
+            else:
+                xf = ops.rfft(x.reshape(B * C, x.shape[2], self.nlon).contiguous(), self.twiddles, self.mmax, True)
+                xf = xf.view(-1, self.mmax, B, C)                                     # [K_loc, M, B, C]
+                xf = distributed_transpose_polar.apply(xf, (3, 0), self.lat_shapes)    # [K, M, B, C_h]
             Ch = xf.shape[3]
             c = ops.legendre_fwd(xf.reshape(self.nlat, self.mmax, B * Ch), self.weights, self.lmax, self.m_off, True)
             c = c.view(self.lmax, -1, B, Ch)
@@ -198,6 +229,13 @@ class DistributedInverseRealSHT(_DistSHTBase):
             Ch = c.shape[3]
             xf = ops.legendre_inv(c.reshape(self.lmax, c.shape[1], B * Ch).contiguous(), self.pct, self.nlat, self.m_off, True)
             xf = xf.view(self.nlat, -1, B, Ch)                                    # [K, M, B, C_h]
+            h = self.comm_size_polar
+            if C == Ch * h and ops.fft_pm_supported(self.nlon, self.mmax, C, Ch):
+                # the latitude chunks are sent as they lie; the received buffer [h, K_loc, M, B, C/h] is read peer-major
+                kl, unit = self.nlat_local, self.mmax * B * Ch
+                xf = _AllToAllFlat.apply(xf, [k * unit for k in self.lat_shapes], [kl * unit] * h, comm.get_group("h"))
+                x = ops.irfft_pm(xf.view(h, kl, self.mmax, B * Ch), self.twiddles, self.nlon, out_dtype, C, Ch)
+                return x.view(B, C, -1, self.nlon)
             xf = distributed_transpose_polar.apply(xf, (0, 3), compute_split_shapes(C, self.comm_size_polar))
             x = ops.irfft(xf.reshape(xf.shape[0], self.mmax, B * C).contiguous(), self.twiddles, self.nlon, out_dtype, True)
             return x.view(B, C, -1, self.nlon)

@@ -108,6 +108,36 @@ def irfft_raw(xf, twiddles, nlon, s0, sm, sh, out_dtype=torch.float32, kmajor=Fa
     return x if x.dtype == out_dtype else x.to(out_dtype)
 
 
+def fft_pm_supported(nlon, mmax, chans, chans_per_peer):
+    """Peer-major Fourier rows (mk_rfft_pm / mk_irfft_pm): split kernels, even channel blocks that are multiples of 24."""
+    return (irfft_bf16_rows(nlon, mmax) and chans_per_peer > 0 and chans % chans_per_peer == 0 and chans_per_peer % 24 == 0
+            and os.environ.get("MK_FFT_LEGACY") != "1")
+
+
+def rfft_pm_raw(x, twiddles, mmax, s0, sm, sh, chans, chans_per_peer):
+    """x real [B*chans, K, N] -> xf complex64 [chans / cpp, K, mmax, B * cpp] (peer-major, see the header)."""
+    _need_cuda(x, twiddles)
+    assert x.dim() == 3 and x.is_contiguous() and x.dtype in (torch.float32, torch.bfloat16)
+    bc, k, n = x.shape
+    xf = torch.empty(chans // chans_per_peer, k, mmax, (bc // chans) * chans_per_peer, dtype=torch.complex64, device=x.device)
+    _lib.check(_lib.load().mk_rfft_pm(x.data_ptr(), 0 if x.dtype == torch.float32 else 1, xf.data_ptr(), twiddles.data_ptr(),
+                                      bc, k, n, mmax, s0, sm, sh, chans, chans_per_peer, _stream()), "mk_rfft_pm")
+    return xf
+
+
+def irfft_pm_raw(xf, twiddles, nlon, s0, sm, sh, chans, chans_per_peer, out_dtype=torch.float32):
+    """xf complex64 [chans / cpp, K, M, B * cpp] -> x [B*chans, K, nlon] (fp32 or bf16 rows)."""
+    _need_cuda(xf, twiddles)
+    assert xf.dim() == 4 and xf.is_contiguous() and xf.dtype == torch.complex64
+    p, k, m, bcp = xf.shape
+    bc = (bcp // chans_per_peer) * chans
+    fused = out_dtype == torch.bfloat16
+    x = torch.empty(bc, k, nlon, dtype=torch.bfloat16 if fused else torch.float32, device=xf.device)
+    _lib.check(_lib.load().mk_irfft_pm(xf.data_ptr(), x.data_ptr(), 1 if fused else 0, twiddles.data_ptr(), bc, k, nlon, m,
+                                       s0, sm, sh, chans, chans_per_peer, _stream()), "mk_irfft_pm")
+    return x if x.dtype == out_dtype else x.to(out_dtype)
+
+
 # Arithmetic of the spectral GEMMs (Legendre, dhconv): "bf16x3" = exact three-way bf16 split of every fp32
 # operand, six bf16 MFMA products, fp32 accumulation (fp32-accurate, csrc/gemm_x3.hip); "f32" = fp32 MFMA
 # (csrc/gemm.hip).  Both meet the 1e-5 parity budget; bf16x3 is the faster one on gfx950.
@@ -365,6 +395,40 @@ class _IRFFT(torch.autograd.Function):
         return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0, ctx.kmajor), None, None, None, None
 
 
+class _RFFTpm(torch.autograd.Function):
+    """rfft into peer-major Fourier rows; adjoint = irfft from them."""
+
+    @staticmethod
+    def forward(ctx, x, twiddles, mmax, chans, cpp):
+        ctx.save_for_backward(twiddles)
+        ctx.cfg = (x.shape[-1], x.dtype, chans, cpp)
+        s = 2.0 * math.pi / x.shape[-1]
+        return rfft_pm_raw(x, twiddles, mmax, s, s, s, chans, cpp)
+
+    @staticmethod
+    def backward(ctx, gxf):
+        (tw,) = ctx.saved_tensors
+        n, dt, chans, cpp = ctx.cfg
+        gx = irfft_pm_raw(gxf.contiguous(), tw, n, 2.0 * math.pi / n, math.pi / n, 2.0 * math.pi / n, chans, cpp, dt)
+        return gx, None, None, None, None
+
+
+class _IRFFTpm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, xf, twiddles, nlon, out_dtype, chans, cpp):
+        ctx.save_for_backward(twiddles)
+        ctx.cfg = (xf.shape[2], chans, cpp)
+        return irfft_pm_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0, chans, cpp, out_dtype)
+
+    @staticmethod
+    def backward(ctx, gx):
+        (tw,) = ctx.saved_tensors
+        mmax, chans, cpp = ctx.cfg
+        if gx.dtype not in (torch.float32, torch.bfloat16):
+            gx = gx.float()
+        return rfft_pm_raw(gx.contiguous(), tw, mmax, 1.0, 2.0, 1.0, chans, cpp), None, None, None, None, None
+
+
 class _LegendreFwd(torch.autograd.Function):
     """xf [Mloc, K, BC] -> c [L, Mloc, BC] with table[m_off + m] (K2)."""
 
@@ -444,6 +508,14 @@ def rfft(x, twiddles, mmax, kmajor=False):
 
 def irfft(xf, twiddles, nlon, out_dtype=torch.float32, kmajor=False):
     return _IRFFT.apply(xf, twiddles, nlon, out_dtype, kmajor)
+
+
+def rfft_pm(x, twiddles, mmax, chans, cpp):
+    return _RFFTpm.apply(x, twiddles, mmax, chans, cpp)
+
+
+def irfft_pm(xf, twiddles, nlon, out_dtype, chans, cpp):
+    return _IRFFTpm.apply(xf, twiddles, nlon, out_dtype, chans, cpp)
 
 
 def legendre_fwd(xf, table, lmax, m_off=0, kmajor=False):

@@ -54,6 +54,19 @@ def _install_cpu_ops():
         t = table[m_off:m_off + mloc, :, :nlat].to(c.dtype)
         return torch.einsum("mlk,lmn->kmn" if kmajor else "mlk,lmn->mkn", t, c).contiguous()
 
+    def rfft_pm(x, tw, mmax, chans, cpp):                                                      # [P, K, M, B * cpp]
+        y = rfft(x, tw, mmax, True)
+        K, M, bc = y.shape
+        return y.view(K, M, bc // chans, chans // cpp, cpp).permute(3, 0, 1, 2, 4).reshape(chans // cpp, K, M, -1).contiguous()
+
+    def irfft_pm(xf, tw, nlon, out_dtype, chans, cpp):
+        P, K, M, bcp = xf.shape
+        y = xf.view(P, K, M, bcp // cpp, cpp).permute(1, 2, 3, 0, 4).reshape(K, M, -1).contiguous()
+        return irfft(y, tw, nlon, out_dtype, True)
+
+    ops.fft_pm_supported = lambda nlon, mmax, chans, cpp: cpp > 0 and chans % cpp == 0 and cpp % 24 == 0
+    ops.rfft_pm, ops.irfft_pm = rfft_pm, irfft_pm
+
     def spec_pack(c_std, l_off=0, m_off=0):
         return c_std.permute(1, 2, 0).contiguous()
 
@@ -161,8 +174,9 @@ def _body_sht(rank, world):
     from makani_amd.distributed import DistributedRealSHT, DistributedInverseRealSHT
     from oracle import spectral as osp
     torch.manual_seed(333)
-    nlat, nlon, lmax, mmax, B, C = 33, 64, 16, 17, 2, 6
-    for grid in ("equiangular", "legendre-gauss"):
+    # C = 6: generic transposes; C = 48 with h = 2: channel blocks of 24 -> the peer-major (copy-free) latitude exchange
+    for grid, (nlat, nlon, lmax, mmax, B, C) in (("equiangular", (33, 64, 16, 17, 2, 6)), ("legendre-gauss", (33, 64, 16, 17, 2, 6)),
+                                                 ("equiangular", (33, 64, 16, 17, 2, 48))):
         f = DistributedRealSHT(nlat, nlon, lmax, mmax, grid)
         fi = DistributedInverseRealSHT(nlat, nlon, lmax, mmax, grid)
         assert f.lat_shapes == [17, 16][: comm.get_size("h")] or comm.get_size("h") == 1

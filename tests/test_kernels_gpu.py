@@ -455,3 +455,22 @@ def test_weighted_mse(dev, dtype):
     assert abs(loss.item() - want.item()) < 1e-5 * abs(want.item())
     tol = 1e-6 if dtype == torch.float32 else 4e-3      # the gradient is rounded to pred's dtype
     assert rel(gp.float().cpu().numpy(), gw.cpu().numpy()) < tol
+
+
+@pytest.mark.parametrize("nlat,nlon,mmax,B,C,cpp", [(5, 480, 33, 2, 48, 24), (3, 1440, 241, 1, 96, 48), (4, 480, 241, 3, 24, 24)])
+def test_fft_peer_major_layout(dev, nlat, nlon, mmax, B, C, cpp):
+    """mk_rfft_pm / mk_irfft_pm: [C/cpp][K][M][B][cpp] holds exactly the numbers of the latitude-major layout."""
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(B * C, nlat, nlon, generator=g).to(dev)
+    tw = ops.fft_twiddles(nlon).to(dev)
+    s = 2 * math.pi / nlon
+    a = ops.rfft_raw(x, tw, mmax, s, s, s, kmajor=True)                         # [K, M, B*C]
+    b = ops.rfft_pm_raw(x, tw, mmax, s, s, s, C, cpp)                             # [P, K, M, B*cpp]
+    want = a.view(nlat, mmax, B, C // cpp, cpp).permute(3, 0, 1, 2, 4).reshape(C // cpp, nlat, mmax, B * cpp)
+    assert torch.equal(b, want)
+    y0 = ops.irfft_raw(a, tw, nlon, 1.0, 1.0, 1.0, kmajor=True)
+    y1 = ops.irfft_pm_raw(b, tw, nlon, 1.0, 1.0, 1.0, C, cpp)
+    assert torch.equal(y0, y1)
+    yb = ops.irfft_pm_raw(b, tw, nlon, 1.0, 1.0, 1.0, C, cpp, torch.bfloat16)
+    assert torch.equal(yb, ops.irfft_raw(a, tw, nlon, 1.0, 1.0, 1.0, torch.bfloat16, kmajor=True))
