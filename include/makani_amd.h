@@ -235,6 +235,24 @@ int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int co
 int mk_conv1x1_fwd(const void* a, const void* x, const void* addend, void* y, int batch, int M, int K,
                    long long P, void* stream);
 
+/* Pixel-column engine (csrc/pce.hip): the same 1x1 convolutions as one persistent kernel per GEMM with the
+ * pointwise passes of layers.py:86-216 / sfnonet.py:239-267 folded into the epilogue:
+ *   acc[b][m][p] = sum_k A[m][k] * x[b][k][p] (+ bias[m]);   aux_out <- acc (bf16, optional: the pre-activation kept for
+ *   the backward pass);   v = gelu ? GELU(acc) : acc;   v *= GELU'(aux_in[b][m][p]) (optional: backward of the activation);
+ *   y = v (+ addend[b][m][p]).
+ * A comes pre-packed (mk_pce_pack) as the MFMA fragment image of W [M][K] (forward) or of W^T (data gradient).
+ * x, y, addend, aux_* are bf16 [B][C][P], P a multiple of 8; K <= 768, and M <= 384 when K > 384; bias is fp32 (or NULL) with
+ * M rounded up to a multiple of 384 readable entries (the epilogue loads it unconditionally); addend and aux_in are exclusive.
+ * Replaces hipBLASLt's mm/addmm behind nn.Conv2d(.., 1) and the separate bias+GELU passes. */
+long long mk_pce_image_bytes(int M, int K);
+int mk_pce_pack(const void* w, int w_dtype /* 0 fp32, 1 bf16 */, int transpose, int M, int K, int ldw, void* img,
+                void* stream);
+int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const void* aux_in,
+                void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream);
+/* Profiling aid (tools/pce_stamps.py): with MK_PCE_DBG=1 in the environment the kernel records s_memtime stamps of
+ * workgroup 0; this copies the 8 x 64 stamps of the last launch to the host. */
+int mk_pce_debug_stamps(unsigned long long* out512);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,10 @@ SIGNATURES = {
     "mk_wmse_bwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_conv1x1_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_conv1x1_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_pce_image_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
+    "mk_pce_pack": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "mk_pce_gemm": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_pce_debug_stamps": (_c_int, [_vp]),
     "mk_instnorm_bwd": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong,
                                  _c_int, _vp]),
 }
@@ -80,8 +84,14 @@ def load():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if not os.path.exists(path):
-        path = _build.build(verbose=False)
+    if _build.stale():
+        # missing, or older than a source / header: rebuild when hipcc is here, never run a stale library silently
+        if _build.have_hipcc():
+            path = _build.build(verbose=False)
+        elif not os.path.exists(path):
+            raise RuntimeError(f"makani_amd: {path} is missing and hipcc is not available to build it")
+        else:
+            raise RuntimeError(f"makani_amd: {path} is older than its sources and hipcc is not available to rebuild it")
     try:
         lib = ctypes.CDLL(path)
     except OSError as e:  # pragma: no cover - environment problem, never silent

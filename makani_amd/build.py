@@ -7,7 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmakani_amd.so")
-SOURCES = ["host.cpp", "fft.hip", "gemm.hip", "gemm_x3.hip", "layout.hip", "diag.hip", "pointwise.hip", "conv_gemm.hip"]
+STAMP = LIB + ".stamp"
+SOURCES = ["host.cpp", "fft.hip", "gemm.hip", "gemm_x3.hip", "layout.hip", "diag.hip", "pointwise.hip", "conv_gemm.hip", "pce.hip"]
 HEADERS = ["common.h", "fft_split.h", os.path.join("..", "..", "include", "makani_amd.h")]
 
 
@@ -18,17 +19,33 @@ def _hipcc():
     raise RuntimeError("hipcc not found; libmakani_amd.so cannot be built")
 
 
-def _stale():
-    if not os.path.exists(LIB):
+def have_hipcc():
+    return any(c and os.path.exists(c) for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"))
+
+
+def _source_digest():
+    """sha256 over every source and header the library is built from (content, not mtime: a snapshot copied to
+    another machine keeps its digest whatever happens to the file times)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(os.environ.get("MK_EXTRA_HIPCC_FLAGS", "").encode() + b"\0")
+    for rel in SOURCES + HEADERS:
+        with open(os.path.join(CSRC, rel), "rb") as f:
+            h.update(rel.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()
+
+
+def stale():
+    """True when libmakani_amd.so is missing or was built from other sources than the ones on disk."""
+    if not os.path.exists(LIB) or not os.path.exists(STAMP):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    with open(STAMP) as f:
+        return f.read().strip() != _source_digest()
 
 
 def build(force=False, verbose=True):
     """Compile every HIP source for gfx950 and link the shared library."""
-    if not force and not _stale():
+    if not force and not stale():
         return LIB
     hipcc = _hipcc()
     objs = []
@@ -38,7 +55,7 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(bdir, src + ".o")
         cmd = [hipcc, "-O3", "-std=c++20", "--offload-arch=gfx950", "-fPIC", "-x", "hip",
-               "-c", os.path.join(CSRC, src), "-o", obj]
+               "-c", os.path.join(CSRC, src), "-o", obj] + os.environ.get("MK_EXTRA_HIPCC_FLAGS", "").split()
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -53,6 +70,14 @@ def build(force=False, verbose=True):
     res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     if res.returncode != 0:
         raise RuntimeError(f"link failed:\n{res.stdout}")
+    # a host stub that silently failed to compile shows up as an undefined symbol at load time: check here, not on the GPU box
+    import ctypes
+    try:
+        ctypes.CDLL(LIB)
+    except OSError as e:
+        raise RuntimeError(f"{LIB} was linked but does not load: {e}") from e
+    with open(STAMP, "w") as f:
+        f.write(_source_digest() + "\n")
     return LIB
 
 

@@ -1,0 +1,688 @@
+// Pixel-column engine: the 1x1 convolutions of the SFNO pointwise stack (encoder, MLP, skips, decoder;
+// makani/models/common/layers.py:86-216, sfnonet.py:239-267) as bf16 MFMA GEMMs on NCHW fields viewed as
+// [C][P = H*W], with the bias / GELU / skip-add / GELU-gradient passes folded into the epilogue.
+//
+//     Y[b][m][p] = epi( sum_k W[m][k] * X[b][k][p] )
+//
+// Shape of the problem on MI355X: M, K are 73..768 channels, P is 1e5..1e6 pixels, so every one of these GEMMs
+// sits at or below the bf16 ridge (intensity M*K/(M+K) <= 256 flop per HBM byte): the job is to read X once, write Y
+// once and keep everything else on chip.  One persistent 512-thread workgroup per CU walks over 128-pixel tiles:
+//
+//   * the X tile [K][128 px] is fetched ONCE by LDS-DMA (global_load_lds_dwordx4, waves 6-7, issued a whole tile
+//     ahead) and each wave pulls its 32 pixel columns out of it into registers as MFMA B fragments with the
+//     transposing LDS read (ds_read_b64_tr_b16) -- the activations then stay in registers for the whole tile;
+//   * the weights are pre-packed once per call (mk_pce_pack) into the exact LDS image of the A fragments
+//     (1 KB per 32 rows x 16 k fragment, lane-linear) and streamed from L2 through a two-slot LDS-DMA ring by
+//     waves 0-5, one slot (all rows x 32 k) ahead of the MFMAs; a fragment read is one conflict-free ds_read_b128;
+//   * wave (pg, mh) owns pixel columns 32*pg.. and the output rows of half mh: 6 accumulators of 32x32 (96 VGPRs) +
+//     24 resident B fragments (96 VGPRs) -> 2 waves per SIMD, which cover each other's LDS / DMA waits;
+//   * the two DMA streams are issued by DIFFERENT waves because vmcnt retires in issue order: a wave that waits
+//     for its next weight slot must not have the (much longer) HBM fetch of the next X tile queued in front of it.
+//
+// K <= 384 per phase; 384 < K <= 768 runs as two K phases into the same accumulators (the second half of the X
+// tile is fetched while the first half is being multiplied).  M > 384 runs as passes of 384 rows over the same
+// resident X fragments.
+#include "common.h"
+#include "../../include/makani_amd.h"
+
+#include <hip/hip_bf16.h>
+#include <cstdint>
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int PT = 512;         // threads: 8 waves = 4 pixel groups x 2 row halves
+constexpr int PN = 128;         // pixels per tile
+constexpr int XROW = PN * 2;    // bytes of one k row of the X tile in LDS
+constexpr int PCE_KPHASE = 384; // k rows resident per phase
+
+struct PceParams {
+    const __hip_bfloat16* x;       // [B][K][P]
+    const char* wimg;              // mk_pce_pack image
+    const char* zeros;             // 64 zero bytes behind the image (source of masked DMA lanes)
+    __hip_bfloat16* y;             // [B][M][P]
+    const float* bias;             // [M] or null
+    const __hip_bfloat16* addend;  // [B][M][P] or null: y += addend
+    const __hip_bfloat16* aux_in;  // [B][M][P] or null: y *= gelu'(aux_in)   (applied before the addend)
+    __hip_bfloat16* aux_out;       // [B][M][P] or null: pre-activation (acc + bias) stored here
+    int gelu;                      // y = gelu(acc + bias)
+    int M, Mtot, K, B;             // M: rows of this launch (one pass), Mtot: rows of the whole field (batch stride)
+    long long P, tiles_per_b, ntiles;
+    unsigned long long* dbg;       // MK_PCE_DBG: s_memtime stamps of workgroup 0 (8 waves x 64 slots), else null
+    int exp;                       // MK_PCE_EXP ablations (wrong results): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no X DMA
+};
+
+// ---- GELU (exact erf form, makani uses nn.GELU()) on the VALU budget of an epilogue --------------------------
+// Phi(x) through erfc(|x|/sqrt2) with the Abramowitz-Stegun 7.1.26 rational-exponential form (|error| < 1.5e-7
+// absolute on erf): 2 transcendentals + ~12 FMAs instead of ~30 instructions of erff().  The results are rounded
+// to bf16 (2^-9 relative) right after.
+struct PhiPair {
+    float Phi, phi;   // standard normal CDF and PDF at x
+};
+__device__ __forceinline__ PhiPair normal_cdf_pdf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // exp(-x^2/2)
+    const float half_erfc = 0.5f * q * t * e;                               // 0.5 erfc(|x|/sqrt2) = Phi(-|x|)
+    PhiPair r;
+    r.Phi = x < 0.f ? half_erfc : 1.0f - half_erfc;
+    r.phi = 0.3989422804014327f * e;
+    return r;
+}
+__device__ __forceinline__ float gelu_f(float x) { return x * normal_cdf_pdf(x).Phi; }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const PhiPair c = normal_cdf_pdf(x);
+    return fmaf(x, c.phi, c.Phi);
+}
+
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
+    const __hip_bfloat16 h = __float2bfloat16(v);
+    return *reinterpret_cast<const unsigned short*>(&h);
+}
+
+// ---- LDS-DMA and hand-scheduled LDS reads ----------------------------------------------------------------------
+// The compiler treats an outstanding LDS-DMA as a pending write to ALL of LDS and drains vmcnt(0) in front of the
+// next LDS read it can see; the weight-fragment reads therefore go through inline asm with hand-counted waits.
+__device__ __forceinline__ void dma16(const void* gptr, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int OFF>
+__device__ __forceinline__ bf16x8 lds_read_frag(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return __builtin_bit_cast(bf16x8, v);
+}
+template <int OFF>
+__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+    u32x4 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_b128(uint32_t addr, u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+// low / high 16 bits of a VGPR
+template <int OFF>
+__device__ __forceinline__ void lds_write_b16_lo(uint32_t addr, uint32_t v) {
+    asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void lds_write_b16_hi(uint32_t addr, uint32_t v) {
+    asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+template <int OFF>
+__device__ __forceinline__ u32x2 lds_read_tr16(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    const bf16x2 t = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(uint32_t, t);
+}
+template <int N>
+__device__ __forceinline__ void wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// raw s_barrier (no vmcnt(0) fence: LDS-DMA may stay in flight across it) between compiler-level memory fences
+__device__ __forceinline__ void block_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+__device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
+__device__ __forceinline__ uint32_t lds_addr(const char* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
+// One weight slot = all 2*TH row tiles of one k16 step; this wave (row half mh) multiplies TH of them, in groups of
+// NF fragments: NF reads in flight, each MFMA issued as soon as its fragment has arrived.
+template <int NF, int T0, int I>
+struct FragLoop {
+    static __device__ __forceinline__ void issue(uint32_t a, bf16x8 (&af)[NF]) {
+        af[I] = lds_read_frag<(T0 + I) * 1024>(a);
+        if constexpr (I + 1 < NF) FragLoop<NF, T0, I + 1>::issue(a, af);
+    }
+    template <int TH>
+    static __device__ __forceinline__ void mfma(const bf16x8 (&af)[NF], const bf16x8& b, f32x16 (&acc)[TH]) {
+        wait_lgkm<NF - 1 - I>();
+        acc[T0 + I] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, af[I], acc[T0 + I], 0, 0, 0);   // D[pixel][m]
+        if constexpr (I + 1 < NF) FragLoop<NF, T0, I + 1>::template mfma<TH>(af, b, acc);
+    }
+};
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// ---- epilogue of one pass -----------------------------------------------------------------------------------------
+// The MFMAs run "transposed" (A = pixel fragment, B = weight fragment), so an accumulator holds its 32 output rows m on
+// the lanes and the 32 pixels in the registers, 4 consecutive pixels per register quad.  Every 32 x 32 tile goes through
+// a wave-private 2 KB LDS tile [32 rows][32 px] bf16: written as 8 bytes per lane (one quad), read back as 16 bytes per
+// lane (4 lanes per 64-byte row segment) and stored with global_store_dwordx4; addend / aux_in tiles take the same
+// way in reverse.  The four 16-byte chunks of a row are rotated by (row >> 1) so neither direction piles onto one bank.
+// All LDS traffic here is inline asm: the compiler would drain the LDS-DMA queue (vmcnt(0)) in front of every LDS
+// access it can see.
+struct EpiAddr {
+    uint32_t st_acc;                // + 16 * ((g + rot) & 3): this lane's row in accumulator layout (8-byte quads)
+    int rot;                        // (m_local >> 1) & 3
+    uint32_t st_lin;                // this lane's 16-byte piece of the linear view (second piece: + 1024)
+    int row_lin, px_lin;            // linear piece q: row = 16 q + row_lin, pixel offset px_lin
+};
+
+template <int OFF>
+__device__ __forceinline__ void lds_write_b64(uint32_t addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ u32x2 lds_read_b64(uint32_t addr) {
+    u32x2 v;
+    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
+
+// HAS_IN is a template parameter and the bias load is unconditional on purpose: the compiler's waitcnt pass is path
+// insensitive, and a VGPR load that sits behind a run-time `if` stays "possibly pending" for it after the join -- it then
+// drains vmcnt(0) in the middle of the next tile's MFMA loop, where those registers are reused (measured: 2,300 cycles
+// per weight group, the whole HBM latency of the X pieces in flight).
+template <int TH, bool HAS_IN>
+__device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[TH], const EpiAddr& ea, int m_first, int m_local,
+                                             long long tile_base /* b*M*P + n0 + 32 pg */, bool px_ok) {
+    const unsigned short* in = reinterpret_cast<const unsigned short*>(p.aux_in ? p.aux_in : p.addend);
+    constexpr bool has_in = HAS_IN;
+    const bool mul_gelu_grad = p.aux_in != nullptr;
+    u32x4 pf[2][2];
+    auto fetch = [&](int t, u32x4 (&dst)[2]) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int m = m_first + 32 * t + 16 * q + ea.row_lin;
+            // rows / pixels outside the field read the zero block behind the weight image: no branch around the load
+            const void* src = (m < p.M && px_ok) ? (const void*)(in + tile_base + (long long)m * p.P + ea.px_lin) : (const void*)p.zeros;
+            dst[q] = *reinterpret_cast<const u32x4*>(src);
+        }
+    };
+    auto quad_addr = [&](int g) { return ea.st_acc + 16 * ((g + ea.rot) & 3); };
+    auto flush = [&](unsigned short* out, int t) {      // staging tile -> global, 16 bytes per lane
+        wait_lgkm<0>();
+        const u32x4 a = lds_read_b128<0>(ea.st_lin);
+        const u32x4 b = lds_read_b128<1024>(ea.st_lin);
+        wait_lgkm<0>();
+        const int m0 = m_first + 32 * t + ea.row_lin;
+        if (px_ok) {
+            if (m0 < p.M) *reinterpret_cast<u32x4*>(out + tile_base + (long long)m0 * p.P + ea.px_lin) = a;
+            if (m0 + 16 < p.M) *reinterpret_cast<u32x4*>(out + tile_base + (long long)(m0 + 16) * p.P + ea.px_lin) = b;
+        }
+    };
+    auto stage = [&](const float (&v)[16]) {            // accumulator layout -> staging tile
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            u32x2 q;
+            q[0] = pack_bf16x2(v[4 * g], v[4 * g + 1]);
+            q[1] = pack_bf16x2(v[4 * g + 2], v[4 * g + 3]);
+            lds_write_b64<0>(quad_addr(g), q);
+        }
+    };
+    if constexpr (has_in) fetch(0, pf[0]);
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = acc[t][r];
+        {
+            const float bv = p.bias[m_first + 32 * t + m_local];    // always there (zeros if the layer has none), padded to 64 TH
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] += bv;
+        }
+        if (p.aux_out) {
+            stage(v);
+            flush(reinterpret_cast<unsigned short*>(p.aux_out), t);
+        }
+        if (p.gelu) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
+        }
+        if constexpr (has_in) {
+            if (t + 1 < TH) fetch(t + 1, pf[(t + 1) % 2]);
+            lds_write_b128<0>(ea.st_lin, pf[t % 2][0]);
+            lds_write_b128<1024>(ea.st_lin, pf[t % 2][1]);
+            wait_lgkm<0>();
+            u32x2 q[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) q[g] = lds_read_b64(quad_addr(g));
+            wait_lgkm<0>();
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float i0 = __uint_as_float(q[g][0] << 16), i1 = __uint_as_float(q[g][0] & 0xFFFF0000u);
+                const float i2 = __uint_as_float(q[g][1] << 16), i3 = __uint_as_float(q[g][1] & 0xFFFF0000u);
+                if (mul_gelu_grad) {
+                    v[4 * g] *= gelu_grad_f(i0); v[4 * g + 1] *= gelu_grad_f(i1);
+                    v[4 * g + 2] *= gelu_grad_f(i2); v[4 * g + 3] *= gelu_grad_f(i3);
+                } else {
+                    v[4 * g] += i0; v[4 * g + 1] += i1; v[4 * g + 2] += i2; v[4 * g + 3] += i3;
+                }
+            }
+        }
+        stage(v);
+        flush(reinterpret_cast<unsigned short*>(p.y), t);
+    }
+}
+
+// KSP: k16 steps per K phase (2, 6 or 12: phases of <= 192 k rows), NPH: phases (1, 2, 4), TH: 32-row tiles per wave.
+//
+// Schedule of one workgroup (all 8 waves alike).  The weight stream is cut into GROUPS of two k16 steps (24 KB at
+// TH = 6) and double-buffered; one iteration = { wait for my pieces of group g, barrier, put group g + 1 and two
+// pieces of a coming X region in flight, 12 fragment reads + 12 MFMAs per wave on group g }.  vmcnt retires in issue
+// order, so a wave always issues its weight pieces BEFORE its X pieces: the wait for the weights is then
+// "all but my youngest cx operations", which leaves the X pieces (HBM latency) in flight for another iteration.
+// X pieces go out in the first groups of a phase only, so the vmcnt(0) waits of its later groups have retired them
+// long before the region is read (two phases later) and before the epilogue's stores are queued.
+template <int KSP, int NPH, int TH, bool HAS_IN>
+__global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
+    constexpr int SLOT = 2 * TH * 1024;          // 2 TH row tiles x one k16 step
+    constexpr int GS = 2;                        // k16 steps per group
+    constexpr int GROUP = GS * SLOT;
+    constexpr int NG = KSP / GS;                 // groups per phase
+    constexpr int NPG = GS * 2 * TH;             // 1 KB weight pieces per group, piece q issued by wave q % 8
+    constexpr int NREG = NPH > 1 ? 2 : 1;        // X regions in LDS: phase ph lives in region ph & 1
+    constexpr int REG_BYTES = 16 * KSP * XROW;   // one region = the k rows of one phase x 128 px
+    constexpr int NXP = 4 * KSP;                 // 1 KB pieces per X region (4 k rows each)
+    constexpr int XG = (NXP + 15) / 16;          // groups of a phase that carry X pieces (2 per wave and group)
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    char* XS = lds;
+    char* WB = lds + NREG * REG_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pg = wave & 3, mh = wave >> 2;
+    constexpr int ngroup_tile = NPH * NG;
+    const int ntiles = (int)p.ntiles, tiles_per_b = (int)p.tiles_per_b;
+
+    // Per-lane addressing of the X fragments and of the epilogue is recomputed from an opaque copy of the lane id where
+    // it is used (once per tile): kept live across the MFMA loop it would be spilled, and a scratch reload inside the
+    // epilogue waits behind the stores queued before it.
+    auto opaque_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+
+    // ---- DMA issue: every wave-instruction is issued with all lanes (lanes outside the field or past K fetch from a
+    //      zero block behind the weight image), so the vmcnt bookkeeping is static and LDS never keeps stale rows ----
+    const char* w_lane = p.wimg + lane * 16 + wave * 1024;
+    auto issue_group = [&](int group_in_tile, int buf) {
+        const char* src = w_lane + (long long)group_in_tile * GROUP;
+        char* dst = WB + buf * GROUP + wave * 1024;
+#pragma unroll
+        for (int q = 0; q < (NPG + 7) / 8; ++q)
+            if (wave + 8 * q < NPG) dma16(src + q * 8192, dst + q * 8192);
+    };
+    // X region image: k row r at r * 256 bytes, its 16 chunks of 8 pixels rotated by 4 * (r & 3) so that the 4 rows x
+    // 4 chunks a transposing read touches sit on 16 different 16-byte bank slots.  Piece n = k rows 4 n .. 4 n + 3.
+    struct XTarget {
+        const __hip_bfloat16* src;    // this lane's source of piece 0 (k row = lane >> 4)
+        char* dst;                    // LDS region
+        int krow0;                    // first k row of the phase
+        bool lane_ok;                 // this lane's pixels are inside the field
+        bool active;
+    };
+    auto x_target = [&](int tile, int phase) {
+        XTarget t;
+        const int b = tile / tiles_per_b;
+        const int l = opaque_lane();
+        const int x_chunk = ((l & 15) - 4 * ((l >> 4) & 3)) & 15;   // global chunk this lane fetches
+        const long long n = (long long)(tile - b * tiles_per_b) * PN + x_chunk * 8;
+        t.krow0 = phase * 16 * KSP + (l >> 4);
+        t.src = p.x + ((long long)b * p.K + t.krow0) * p.P + n;
+        t.dst = XS + (phase & (NREG - 1)) * REG_BYTES;
+        t.lane_ok = n < p.P;
+        t.active = true;
+        return t;
+    };
+    // pieces 16 xg + 2 wave + {0, 1} of the target region; returns how many this wave issued
+    auto issue_x = [&](const XTarget& t, int xg) {
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = 16 * xg + 2 * wave + j;
+            if (n < NXP) {
+                const void* src = (t.krow0 + 4 * n < p.K && t.lane_ok) ? (const void*)(t.src + (long long)(4 * n) * p.P)
+                                                                       : (const void*)p.zeros;
+                dma16(src, t.dst + n * 1024);
+                ++cnt;
+            }
+        }
+        return cnt;
+    };
+
+    int tile = blockIdx.x;
+    int g = 0;           // running group counter: group g lives in ring buffer g & 1
+    int gi = 0;          // groups issued so far
+    int landed = 0;      // groups known to have landed (drained before the last epilogue)
+    int si = 0;          // group-in-tile index of the next group to issue
+    bool si_next = false;   // ... which belongs to the next tile
+    int cx = 0;          // X pieces this wave issued after its last weight pieces
+    auto issue_next_group = [&](int next_tile) {
+        if (si_next && next_tile >= ntiles) return;
+        if (!(p.exp & 4)) issue_group(si, gi & 1);
+        ++gi;
+        if (++si == ngroup_tile) {
+            si = 0;
+            si_next = true;
+        }
+    };
+    if (tile < ntiles) {
+        issue_next_group(tile + gridDim.x);
+        for (int ph = 0; ph < NREG; ++ph) {
+            const XTarget t = x_target(tile, ph);
+            for (int xg = 0; xg < XG; ++xg) issue_x(t, xg);
+        }
+        wait_vm0();      // the first tile's X regions (the weight group with them): simplest to drain here
+        landed = gi;
+    }
+
+    const uint32_t a_lane = lds_addr(WB) + mh * TH * 1024 + lane * 16;   // this wave's weight fragments inside a ring buffer
+
+#ifdef MK_PCE_STAMPS   // profiling build only (tools/pce_stamps.py): the stamps cost registers in the hot loop
+    int stamp_n = 0;
+    auto stamp = [&]() {
+        if (p.dbg && blockIdx.x == 0 && tile == (int)gridDim.x * 3 && stamp_n < 64) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (lane == 0) p.dbg[wave * 64 + stamp_n] = t;
+            ++stamp_n;
+        }
+    };
+#else
+    auto stamp = [&]() {};
+#endif
+    for (; tile < ntiles; tile += gridDim.x) {
+        const int next_tile = tile + gridDim.x;
+        const int b = tile / tiles_per_b;
+        const long long n0 = (long long)(tile - b * tiles_per_b) * PN;
+        f32x16 acc[TH];
+        stamp();   // 0: tile start
+        if (si_next) si_next = false;               // the stream's "next tile" is this tile now
+#pragma unroll
+        for (int i = 0; i < TH; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+        auto run_phase = [&](const int phase) {
+            // ---- X phase: every wave has retired its pieces of this region (see the schedule above); the barrier makes
+            //      them visible; pull this wave's pixel columns into registers ----
+            block_sync();
+            stamp();   // 1
+            bf16x8 xf[KSP];
+            {
+                const int l = opaque_lane();
+                const int rowq = (l & 15) >> 2;
+                const int ch = 4 * pg + 2 * ((l >> 4) & 1) + ((l & 3) >> 1);
+                const char* xfrag_lane = XS + (phase & (NREG - 1)) * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
+                                         ((ch + 4 * rowq) & 15) * 16 + (l & 1) * 8;
+                if (!(p.exp & 16))
+#pragma unroll
+                for (int s = 0; s < KSP; ++s) {
+                    const char* q = xfrag_lane + s * 16 * XROW;
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(q));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(q + 4 * XROW));
+                    xf[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            block_sync();                                       // the region may be overwritten
+            stamp();   // 2
+            // fetched into this region while the phase computes: the phase NREG ahead (of this tile, or of the next one)
+            XTarget xt;
+            xt.active = false;
+            if (!(p.exp & 8)) {
+                if (phase + NREG < NPH) xt = x_target(tile, phase + NREG);
+                else if (next_tile < ntiles) xt = x_target(next_tile, phase + NREG - NPH);
+            }
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                stamp();   // 3 + 3 gq
+                if (g >= landed) {                              // my pieces of group g: all but my cx youngest operations
+                    if (cx >= 2) wait_vm<2>();
+                    else if (cx == 1) wait_vm<1>();
+                    else wait_vm0();
+                }
+                stamp();   // 4 + 3 gq
+                if (!(p.exp & 32)) block_sync();                // group g complete; everyone is done with group g - 1
+                stamp();   // 5 + 3 gq
+                issue_next_group(next_tile);
+                cx = (gq < XG && xt.active) ? issue_x(xt, gq) : 0;
+                if (!(p.exp & 2)) {
+                    const uint32_t a = a_lane + (g & 1) * GROUP;
+                    bf16x8 af[TH];
+#pragma unroll
+                    for (int s = 0; s < GS; ++s) {
+                        FragLoop<TH, 0, 0>::issue(a + s * SLOT, af);
+                        FragLoop<TH, 0, 0>::template mfma<TH>(af, xf[GS * gq + s], acc);
+                    }
+                }
+                ++g;
+            }
+        };
+        run_phase(0);
+        if constexpr (NPH >= 2) run_phase(1);
+        if constexpr (NPH >= 4) {
+            run_phase(2);
+            run_phase(3);
+        }
+        stamp();   // epilogue start
+        // everything this wave has in flight (the next weight group, late X pieces) lands before the epilogue's stores are
+        // queued behind it: no later wait has to sit out a store's round trip
+        wait_vm0();
+        landed = gi;
+        cx = 0;
+        stamp();
+        if (!(p.exp & 1)) {
+            EpiAddr ea;
+            const int l = opaque_lane();
+            const uint32_t stg = lds_addr(WB) + 2 * GROUP + wave * 2048;    // wave-private [32 rows][32 px] bf16 tile
+            const int ml = l & 31;
+            ea.rot = (ml >> 1) & 3;
+            ea.st_acc = stg + ml * 64 + (l >> 5) * 8;
+            ea.row_lin = l >> 2;
+            ea.px_lin = (l & 3) * 8;
+            ea.st_lin = stg + ea.row_lin * 64 + (((l & 3) + (ea.row_lin >> 1)) & 3) * 16;
+            const long long px0 = n0 + 32 * pg;
+            pce_epilogue<TH, HAS_IN>(p, acc, ea, mh * 32 * TH, ml, (long long)b * p.Mtot * p.P + px0, px0 + ea.px_lin < p.P);
+        } else {
+#pragma unroll
+            for (int t = 0; t < TH; ++t) keep_alive(acc[t]);
+        }
+        stamp();   // epilogue end
+    }
+    // drain: nothing may be in flight into LDS when the workgroup's LDS is released
+    wait_vm0();
+}
+
+// ---- weight image ----------------------------------------------------------------------------------------------
+// element (pass, k16 step ks, row tile rt, lane, j)  <-  A[m][k],  m = pass*64*TH + rt*32 + (lane & 31),
+// k = 16 ks + 8 (lane >> 5) + j;  A = W or W^T;  one slot = the 2 TH fragments of one k16 step; 32 zero elements at the end
+template <typename T>
+__global__ void pce_pack_kernel(const T* __restrict__ w, int transpose, int M, int K, int ldw, int TH, int steps_per_pass,
+                                unsigned short* __restrict__ img, long long core, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    if (idx >= core) {
+        img[idx] = 0;
+        return;
+    }
+    const int j = (int)(idx & 7);
+    const int lane = (int)((idx >> 3) & 63);
+    long long f = idx >> 9;                 // fragment index
+    const int rt = (int)(f % (2 * TH));
+    f /= 2 * TH;
+    const int pass = (int)(f / steps_per_pass), ks = (int)(f % steps_per_pass);
+    const int m = pass * 64 * TH + rt * 32 + (lane & 31);
+    const int k = 16 * ks + 8 * (lane >> 5) + j;
+    float v = 0.f;
+    if (m < M && k < K) v = (float)(transpose ? w[(long long)k * ldw + m] : w[(long long)m * ldw + k]);
+    img[idx] = f32_to_bf16_bits(v);
+}
+
+// zero bias for layers without one (the epilogue's bias load is unconditional); first use must not be inside a capture
+static const float* pce_zero_bias() {
+    static float* z = [] {
+        float* q = nullptr;
+        if (hipMalloc(&q, 4096) != hipSuccess) return (float*)nullptr;
+        (void)hipMemset(q, 0, 4096);
+        return q;
+    }();
+    return z;
+}
+
+static unsigned long long* pce_dbg_buffer() {
+    static unsigned long long* d = [] {
+        unsigned long long* q = nullptr;
+        if (getenv("MK_PCE_DBG")) {
+            if (hipMalloc(&q, 8 * 64 * 8) != hipSuccess) return (unsigned long long*)nullptr;
+            (void)hipMemset(q, 0, 8 * 64 * 8);
+        }
+        return q;
+    }();
+    return d;
+}
+
+struct PceCfg {
+    int KSP, NPH, TH, npass;
+};
+static bool pce_config(int M, int K, PceCfg* c) {
+    if (M <= 0 || K <= 0 || K > 768) return false;
+    c->KSP = K > 96 ? 12 : (K > 32 ? 6 : 2);            // k16 steps per phase
+    c->NPH = K > 384 ? 4 : (K > 192 ? 2 : 1);           // phases of 16 KSP rows (K in (384, 576] pads to four)
+    c->TH = M > 128 ? 6 : (M > 64 ? 2 : 1);
+    c->npass = mk::ceil_div(M, 64 * c->TH);
+    return true;
+}
+static long long pce_image_core_bytes(const PceCfg& c) { return (long long)c.npass * c.NPH * c.KSP * 2 * c.TH * 1024; }
+
+template <int KSP, int NPH, int TH, bool HAS_IN>
+static int pce_launch(const PceParams& p, hipStream_t st) {
+    constexpr int LDS = (NPH > 1 ? 2 : 1) * 16 * KSP * XROW + 2 * 2 * 2 * TH * 1024 + 8 * 2048;   // X regions + two weight groups + 8 staging tiles
+    static const bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pce_kernel<KSP, NPH, TH, HAS_IN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        return true;
+    }();
+    (void)once;
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    const long long grid = p.ntiles < ncu ? p.ntiles : ncu;
+    hipLaunchKernelGGL((pce_kernel<KSP, NPH, TH, HAS_IN>), dim3((unsigned)grid), dim3(PT), LDS, st, p);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" long long mk_pce_image_bytes(int M, int K) {
+    PceCfg c;
+    if (!pce_config(M, K, &c)) return 0;
+    return pce_image_core_bytes(c) + 64;    // + the zero block masked DMA lanes read
+}
+
+extern "C" int mk_pce_pack(const void* w, int w_dtype, int transpose, int M, int K, int ldw, void* img, void* stream) {
+    MK_REQUIRE(w && img, "null pointer");
+    MK_REQUIRE(w_dtype == 0 || w_dtype == 1, "w_dtype must be 0 (fp32) or 1 (bf16)");
+    PceCfg c;
+    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768; M <= 384 when K > 384)");
+    MK_REQUIRE(ldw >= (transpose ? M : K), "leading dimension too small");
+    const long long total = (pce_image_core_bytes(c) + 64) / 2;
+    const int spp = c.NPH * c.KSP;
+    const long long nblk = (total + 255) / 256;
+    if (w_dtype == 0)
+        hipLaunchKernelGGL(pce_pack_kernel<float>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const float*)w,
+                           transpose, M, K, ldw, c.TH, spp, (unsigned short*)img, total - 32, total);
+    else
+        hipLaunchKernelGGL(pce_pack_kernel<__hip_bfloat16>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
+                           (const __hip_bfloat16*)w, transpose, M, K, ldw, c.TH, spp, (unsigned short*)img, total - 32, total);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend,
+                           const void* aux_in, void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream) {
+    MK_REQUIRE(x && wimg && y, "null pointer");
+    MK_REQUIRE(batch > 0 && M > 0 && K > 0 && P > 0, "bad sizes");
+    MK_REQUIRE((P % 8) == 0, "P = H*W must be a multiple of 8 (16-byte row alignment)");
+    MK_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wimg & 15) == 0, "x and the weight image must be 16-byte aligned");
+    PceCfg c;
+    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768; M <= 384 when K > 384)");
+    static const int pexp = [] { const char* e = getenv("MK_PCE_EXP"); return e ? atoi(e) : 0; }();
+    MK_REQUIRE(!(addend && aux_in), "addend and aux_in are exclusive");
+    hipStream_t st = (hipStream_t)stream;
+    const float* zero_bias = bias ? nullptr : pce_zero_bias();
+    MK_REQUIRE(bias || zero_bias, "cannot allocate the zero bias");
+    const long long tiles_per_b = (P + PN - 1) / PN;
+    MK_REQUIRE(tiles_per_b * batch < 2147483647LL, "too many pixel tiles");
+    // M > 64 TH rows: one launch per pass of 64 TH rows (each pass streams X again)
+    const int rows_per_pass = 64 * c.TH;
+    const long long img_per_pass = (long long)c.NPH * c.KSP * 2 * c.TH * 1024;
+    const char* zeros = (const char*)wimg + pce_image_core_bytes(c);
+    for (int pass = 0; pass < c.npass; ++pass) {
+        const long long roff = (long long)pass * rows_per_pass;
+        PceParams p;
+        p.x = (const __hip_bfloat16*)x;
+        p.wimg = (const char*)wimg + pass * img_per_pass;
+        p.zeros = zeros;
+        p.y = (__hip_bfloat16*)y + roff * P;
+        p.bias = bias ? bias + roff : zero_bias;
+        p.addend = addend ? (const __hip_bfloat16*)addend + roff * P : nullptr;
+        p.aux_in = aux_in ? (const __hip_bfloat16*)aux_in + roff * P : nullptr;
+        p.aux_out = aux_out ? (__hip_bfloat16*)aux_out + roff * P : nullptr;
+        p.gelu = gelu;
+        p.M = M - (int)roff < rows_per_pass ? M - (int)roff : rows_per_pass;
+        p.Mtot = M;
+        p.K = K;
+        p.B = batch;
+        p.P = P;
+        p.tiles_per_b = tiles_per_b;
+        p.ntiles = tiles_per_b * batch;
+        p.dbg = pce_dbg_buffer();
+        p.exp = pexp;
+        bool done = false;
+#define MK_PCE_CASE(KSP_, NPH_, TH_) \
+        if (!done && c.KSP == KSP_ && c.NPH == NPH_ && c.TH == TH_) {                                         \
+            if (p.addend || p.aux_in) pce_launch<KSP_, NPH_, TH_, true>(p, st);                               \
+            else pce_launch<KSP_, NPH_, TH_, false>(p, st);                                                   \
+            done = true;                                                                                        \
+        }
+        MK_PCE_CASE(2, 1, 1) MK_PCE_CASE(2, 1, 2) MK_PCE_CASE(2, 1, 6)
+        MK_PCE_CASE(6, 1, 1) MK_PCE_CASE(6, 1, 2) MK_PCE_CASE(6, 1, 6)
+        MK_PCE_CASE(12, 1, 1) MK_PCE_CASE(12, 1, 2) MK_PCE_CASE(12, 1, 6)
+        MK_PCE_CASE(12, 2, 1) MK_PCE_CASE(12, 2, 2) MK_PCE_CASE(12, 2, 6)
+        MK_PCE_CASE(12, 4, 1) MK_PCE_CASE(12, 4, 2) MK_PCE_CASE(12, 4, 6)
+#undef MK_PCE_CASE
+        MK_REQUIRE(done, "no kernel instance for this shape");
+        MK_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+// debug: s_memtime stamps of workgroup 0, fourth tile, of the last launch (MK_PCE_DBG=1): 8 waves x 64 stamps
+extern "C" int mk_pce_debug_stamps(unsigned long long* out512) {
+    MK_REQUIRE(out512, "null pointer");
+    unsigned long long* d = pce_dbg_buffer();
+    MK_REQUIRE(d, "MK_PCE_DBG is not set");
+    MK_REQUIRE(hipMemcpy(out512, d, 8 * 64 * 8, hipMemcpyDeviceToHost) == hipSuccess, "copy failed");
+    return 0;
+}

@@ -82,30 +82,127 @@ class _PointwiseConv(torch.autograd.Function):
         return gx, gw, ga
 
 
+def _row_sums(t3):
+    """sum over (batch, pixels) of a [B, C, P] field -> fp32 [C] (the HIP row-sum pass of the instance norm)."""
+    from . import ops
+    return ops.row_sums(t3).view(t3.shape[0], t3.shape[1]).sum(0)
+
+
+class _PceConv(torch.autograd.Function):
+    """y[b] = W @ x[b] (+ bias) (+ addend[b]) on bf16 ``[B, C, P]`` fields, one pixel-column-engine launch
+    (csrc/pce.hip) each way; the weight gradient comes from the bf16 MFMA wgrad kernel in fp32."""
+
+    @staticmethod
+    def forward(ctx, x3, w, bias, addend):
+        from . import ops
+        ctx.save_for_backward(x3, w)
+        ctx.has = (bias is not None, addend is not None)
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return ops.pce_gemm(x3, ops.pce_pack(w), w.shape[0], bias=bias, addend=addend)
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x3, w = ctx.saved_tensors
+        has_bias, has_addend = ctx.has
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.pce_gemm(gy, ops.pce_pack(w, transpose=True), w.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv1x1_wgrad_raw(gy, x3).to(w.dtype)
+        if has_bias and ctx.needs_input_grad[2]:
+            gb = _row_sums(gy).to(ctx.bias_dtype)
+        return gx, gw, gb, (gy if has_addend else None)
+
+
+class _PceMLP(torch.autograd.Function):
+    """y = W2 @ gelu(W1 @ x + b1) (+ b2): the MLP / encoder / decoder of ``layers.py:86-216`` on bf16 ``[B, C, P]``
+    fields.  Forward: two engine launches, bias + GELU in the epilogue of the first (which also keeps the
+    pre-activation).  Backward: ``gpre = (W2^T gy) * gelu'(pre)`` in one launch, ``gx = W1^T gpre`` in another, the two
+    weight gradients from the wgrad kernel, the bias gradients from row sums.
+
+    ``b2`` may be switched off with ``apply_b2=False`` (the caller normalises the result per channel, which removes any
+    per-channel constant): the parameter stays in the graph and receives the exact gradient of that case -- zero -- so
+    wrappers that expect every parameter to get a gradient (DistributedDataParallel, ``mpu/mappings.py:86-96``) work."""
+
+    @staticmethod
+    def forward(ctx, x3, w1, b1, w2, b2, apply_b2):
+        from . import ops
+        h, pre = ops.pce_gemm(x3, ops.pce_pack(w1), w1.shape[0], bias=b1, want_pre=True, gelu=True)
+        y = ops.pce_gemm(h, ops.pce_pack(w2), w2.shape[0], bias=b2 if (apply_b2 and b2 is not None) else None)
+        ctx.save_for_backward(x3, w1, w2, pre, h)
+        ctx.cfg = (None if b1 is None else b1.dtype, None if b2 is None else (b2.dtype, tuple(b2.shape)), bool(apply_b2))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x3, w1, w2, pre, h = ctx.saved_tensors
+        b1_dtype, b2_info, apply_b2 = ctx.cfg
+        gy = gy.contiguous()
+        gpre = ops.pce_gemm(gy, ops.pce_pack(w2, transpose=True), w2.shape[1], aux_in=pre)
+        gx = gw1 = gb1 = gw2 = gb2 = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.pce_gemm(gpre, ops.pce_pack(w1, transpose=True), w1.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw1 = ops.conv1x1_wgrad_raw(gpre, x3).to(w1.dtype)
+        if b1_dtype is not None and ctx.needs_input_grad[2]:
+            gb1 = _row_sums(gpre).to(b1_dtype)
+        if ctx.needs_input_grad[3]:
+            gw2 = ops.conv1x1_wgrad_raw(gy, h).to(w2.dtype)
+        if b2_info is not None and ctx.needs_input_grad[4]:
+            gb2 = _row_sums(gy).to(b2_info[0]) if apply_b2 else torch.zeros(b2_info[1], dtype=b2_info[0], device=gy.device)
+        return gx, gw1, gb1, gw2, gb2, None
+
+
+def _engine_field(x):
+    """The field as the pixel-column engine takes it (bf16 ``[B, C, P]``, contiguous, P a multiple of 8), or None."""
+    if not (x.is_cuda and x.dim() == 4 and x.is_contiguous() and (x.shape[2] * x.shape[3]) % 8 == 0):
+        return None
+    if os.environ.get("MK_CONV_ENGINE", "pce") != "pce":
+        return None
+    if x.dtype == torch.bfloat16:
+        return x.view(x.shape[0], x.shape[1], -1)
+    if torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16 and x.dtype == torch.float32:
+        return x.view(x.shape[0], x.shape[1], -1).to(torch.bfloat16)
+    return None
+
+
 class Conv1x1(nn.Conv2d):
-    """``nn.Conv2d(cin, cout, 1)`` evaluated as ``W @ x.view(B, C, H*W)`` (+ bias)."""
+    """``nn.Conv2d(cin, cout, 1)`` (same parameters and ``state_dict`` entries) evaluated as a GEMM over the pixels."""
 
     def __init__(self, in_channels, out_channels, bias=True):
         super().__init__(in_channels, out_channels, 1, bias=bias)
 
+    def weight2d(self):
+        return self.weight.view(self.out_channels, self.in_channels)
+
     def forward(self, x, add_bias=True, addend=None):
         """``addend`` (same shape as the output) is added inside the GEMM epilogue: y = addend + conv(x)."""
+        from . import ops
+        B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+        x3 = _engine_field(x) if x.dim() == 4 else None
+        if x3 is not None and ops.pce_supported(self.out_channels, self.in_channels):
+            a3 = None
+            if addend is not None:
+                a3 = addend.contiguous().view(B, self.out_channels, H * W).to(torch.bfloat16)
+            with torch.autocast("cuda", enabled=False):
+                y = _PceConv.apply(x3, self.weight2d(), self.bias if add_bias else None, a3)
+            return y.view(B, self.out_channels, H, W)
         if x.dim() != 4 or not x.is_contiguous() or not x.is_cuda:
             y = F.conv2d(x, self.weight, self.bias if add_bias else None)
             return y if addend is None else y + addend
-        B, C, H, W = x.shape
-        w = self.weight.view(self.out_channels, self.in_channels)
-        # NOTE: torch.matmul(2-D, 3-D) folds through a transposed *copy* of the activation; mm / bmm on
-        # the [C, H*W] row-major view go straight to hipBLASLt with no copy in forward or backward
+        # fp32 fields (no autocast): torch mm / bmm on the [C, H*W] row-major view, HIP wgrad kernel for bf16 only
         if torch.is_autocast_enabled():
-            x3 = x.view(B, C, H * W).to(torch.get_autocast_dtype('cuda'))
+            x3 = x.view(B, x.shape[1], H * W).to(torch.get_autocast_dtype('cuda'))
         else:
-            x3 = x.view(B, C, H * W)
+            x3 = x.view(B, x.shape[1], H * W)
         with torch.autocast("cuda", enabled=False):
             a3 = None
             if addend is not None:
                 a3 = addend.contiguous().view(B, self.out_channels, H * W).to(x3.dtype)
-            y = _PointwiseConv.apply(x3, w, a3)
+            y = _PointwiseConv.apply(x3, self.weight2d(), a3)
         if self.bias is not None and add_bias:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)
@@ -115,23 +212,50 @@ def _is_exact_gelu(m):
     return isinstance(m, nn.GELU) and getattr(m, "approximate", "none") == "none"
 
 
-def run_pointwise_chain(mods, x, skip_last_bias=False):
-    """Evaluate an ``nn.Sequential`` of 1x1 convs / activations / identities, fusing every
-    ``Conv1x1(bias) -> GELU`` pair into one HIP bias+GELU pass over the conv output.
+def _is_noop(m):
+    return isinstance(m, nn.Identity) or (isinstance(m, (nn.Dropout, nn.Dropout2d)) and (m.p == 0.0 or not m.training))
 
-    ``skip_last_bias``: the caller feeds the result straight into an instance norm, which removes any
-    per-channel constant -- the last conv's bias add is then a no-op on the output (and its gradient is
-    identically zero), so the pass over the tensor is skipped.
+
+def _mlp_pattern(mods):
+    """``[Conv1x1, exact GELU, no-ops..., Conv1x1, no-ops...]`` -> (fc1, fc2), else None."""
+    convs = [m for m in mods if isinstance(m, Conv1x1)]
+    if len(convs) != 2 or not isinstance(mods[0], Conv1x1) or len(mods) < 3 or not _is_exact_gelu(mods[1]):
+        return None
+    rest = [m for m in mods[2:] if not _is_noop(m)]
+    if len(rest) != 1 or rest[0] is not convs[1]:
+        return None
+    return convs[0], convs[1]
+
+
+def run_pointwise_chain(mods, x, skip_last_bias=False):
+    """Evaluate an ``nn.Sequential`` of 1x1 convs / activations / identities.
+
+    The two-convolution pattern of ``MLP`` and ``EncoderDecoder`` (conv + bias, exact GELU, conv) runs as one fused
+    autograd node on the pixel-column engine when the field is bf16 (or autocast to it).  Otherwise every
+    ``Conv1x1(bias) -> GELU`` pair is one GEMM plus one HIP bias+GELU pass.
+
+    ``skip_last_bias``: the caller feeds the result straight into an instance norm without running statistics, which
+    removes any per-channel constant -- the last conv's bias add is then a no-op on the output and its gradient is
+    exactly zero, so the add is skipped (the parameter still receives that zero gradient).
     """
     from . import ops
     mods = list(mods)
+    pat = _mlp_pattern(mods)
+    if pat is not None and x.dim() == 4:
+        fc1, fc2 = pat
+        x3 = _engine_field(x)
+        if (x3 is not None and ops.pce_supported(fc1.out_channels, fc1.in_channels)
+                and ops.pce_supported(fc2.out_channels, fc2.in_channels)):
+            with torch.autocast("cuda", enabled=False):
+                y = _PceMLP.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias)
+            return y.view(x.shape[0], fc2.out_channels, x.shape[2], x.shape[3])
     last_conv = max((j for j, m in enumerate(mods) if isinstance(m, Conv1x1)), default=-1)
-    tail_is_identity = all(isinstance(m, nn.Identity) for m in mods[last_conv + 1:])
+    tail_is_noop = all(_is_noop(m) for m in mods[last_conv + 1:])
     i = 0
     while i < len(mods):
         m = mods[i]
-        if skip_last_bias and tail_is_identity and i == last_conv and x.is_cuda:
-            x = m(x, add_bias=False)
+        if skip_last_bias and tail_is_noop and i == last_conv and x.is_cuda and m.bias is not None:
+            x = _ZeroGradBias.apply(m(x, add_bias=False), m.bias)
             i += 1
             continue
         if isinstance(m, Conv1x1) and i + 1 < len(mods) and _is_exact_gelu(mods[i + 1]) and x.is_cuda:
@@ -147,6 +271,19 @@ def run_pointwise_chain(mods, x, skip_last_bias=False):
             x = m(x)
             i += 1
     return x
+
+
+class _ZeroGradBias(torch.autograd.Function):
+    """Identity on ``y`` that keeps a skipped bias in the graph: its gradient in front of an instance norm is zero."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        ctx.meta = (bias.dtype, tuple(bias.shape))
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        return gy, torch.zeros(ctx.meta[1], dtype=ctx.meta[0], device=gy.device)
 
 
 class InstanceNorm2d(nn.InstanceNorm2d):

@@ -355,6 +355,52 @@ def conv1x1_fwd_raw(a, x3, addend=None):
 
 
 # ----------------------------------------------------------------------------
+# pixel-column engine (csrc/pce.hip): 1x1 convolutions with fused epilogues
+# ----------------------------------------------------------------------------
+def pce_supported(m, k):
+    """Shapes the engine is built for: K <= 768, and M <= 384 when K > 384."""
+    return _lib.load().mk_pce_image_bytes(int(m), int(k)) > 0
+
+
+def pce_pack(w, transpose=False):
+    """MFMA fragment image of A = w (``[M, K]``) or A = w^T (``w`` is ``[K, M]``); fp32 or bf16 weights."""
+    _need_cuda(w)
+    assert w.dim() == 2 and w.stride(1) == 1 and w.dtype in (torch.float32, torch.bfloat16)
+    m, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+    lib = _lib.load()
+    nbytes = lib.mk_pce_image_bytes(m, k)
+    if nbytes <= 0:
+        raise ValueError(f"pce_pack: unsupported GEMM shape M={m}, K={k}")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+    _lib.check(lib.mk_pce_pack(w.data_ptr(), 0 if w.dtype == torch.float32 else 1, int(bool(transpose)), m, k, w.stride(0),
+                               img.data_ptr(), _stream()), "mk_pce_pack")
+    return img
+
+
+def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False):
+    """y[b] = epi(A @ x3[b]) on bf16 ``[B, K, P]`` fields (see ``mk_pce_gemm``).  Returns ``y`` or ``(y, pre)`` with
+    ``pre`` the bf16 pre-activation ``A x + bias`` when ``want_pre``."""
+    _need_cuda(x3, wimg)
+    assert x3.dim() == 3 and x3.is_contiguous() and x3.dtype == torch.bfloat16
+    b, k, p = x3.shape
+    for t in (addend, aux_in):
+        if t is not None:
+            assert t.is_contiguous() and t.dtype == torch.bfloat16 and tuple(t.shape) == (b, m, p)
+    bf = None
+    if bias is not None:      # fp32, padded to whole passes of the kernel (its epilogue loads the bias unconditionally)
+        bf = torch.zeros((m + 383) // 384 * 384, dtype=torch.float32, device=x3.device)
+        bf[:m] = bias.detach()
+    y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
+    pre = torch.empty_like(y) if want_pre else None
+    _lib.check(_lib.load().mk_pce_gemm(x3.data_ptr(), wimg.data_ptr(), y.data_ptr(), None if bf is None else bf.data_ptr(),
+                                       None if addend is None else addend.data_ptr(),
+                                       None if aux_in is None else aux_in.data_ptr(),
+                                       None if pre is None else pre.data_ptr(), int(bool(gelu)), b, m, k, p, _stream()),
+               "mk_pce_gemm")
+    return (y, pre) if want_pre else y
+
+
+# ----------------------------------------------------------------------------
 # differentiable operators (all linear in the data: backward = adjoint launch)
 # ----------------------------------------------------------------------------
 class _RFFT(torch.autograd.Function):
@@ -683,6 +729,17 @@ def weighted_mse(pred, tar, wrow, scale=1.0):
         w = wrow.view(1, 1, -1, 1)
         return scale * (((pred.float() - tar) ** 2) * w).sum()
     return _WeightedMSE.apply(pred, tar, wrow.float().contiguous(), scale)
+
+
+def row_sums(t3):
+    """Sum over the last axis of a contiguous [B, C, P] fp32 / bf16 field -> fp32 [B * C] (mk_instnorm_fwd_ex, phase 1)."""
+    _need_cuda(t3)
+    assert t3.dim() == 3 and t3.is_contiguous()
+    b, c, p = t3.shape
+    ws = torch.empty(b * c, 2, dtype=torch.float64, device=t3.device)
+    _lib.check(_lib.load().mk_instnorm_fwd_ex(t3.data_ptr(), 0, 0, 0, 0, ws.data_ptr(), _pw_dtype(t3), b * c, c, p, p, 0.0, 0,
+                                              1, _stream()), "mk_instnorm_fwd_ex")
+    return ws[:, 0].float()
 
 
 def bias_gelu(x, bias):

@@ -123,7 +123,9 @@ class FourierNeuralOperatorBlock(nn.Module):
                 x = x + self.inner_skip(residual)
             if hasattr(self, "act_layer0"):
                 x = self.act_layer0(x)
-        norm1_is_instance = isinstance(self.norm1, (nn.InstanceNorm2d, DistributedInstanceNorm2d))
+        # a per-channel constant cancels only in a norm that uses the statistics of the field itself
+        norm1_is_instance = (isinstance(self.norm1, (nn.InstanceNorm2d, DistributedInstanceNorm2d))
+                             and not getattr(self.norm1, "track_running_stats", False))
         if hasattr(self, "mlp"):
             # a per-channel bias in front of an instance norm cancels exactly: skip that pass
             x = self.mlp(x, skip_last_bias=norm1_is_instance)
@@ -347,7 +349,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             x = self.decoder(x)
 
         if self.big_skip:
-            x = x + self.residual_transform(residual)
+            x = self.residual_transform(residual, addend=x)      # big skip folded into the GEMM epilogue
         return x
 
 

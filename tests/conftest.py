@@ -17,3 +17,12 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session")
+def dev():
+    import torch
+    assert torch.cuda.is_available(), "these tests need an MI355X"
+    from makani_amd import _lib
+    _lib.load()
+    return torch.device("cuda:0")
