@@ -284,6 +284,17 @@ __global__ __launch_bounds__(kT) void instnorm_bwd_apply_kernel(const T* __restr
 
 inline dim3 pw_grid(long long rows, long long P) { return dim3((unsigned)((P + kChunk - 1) / kChunk), (unsigned)rows); }
 
+// Accumulators are zeroed by a kernel, not hipMemsetAsync: under stream capture the memset node of a small buffer whose
+// storage the allocator hands out again inside the same graph was observed to leave stale values on replay
+// (tools/graph_bisect.py: a bias gradient summed into such a buffer turned non-finite from the second replay on).
+__global__ void zero_doubles_kernel(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+static inline void zero_doubles(double* p, int n, hipStream_t st) {
+    hipLaunchKernelGGL(zero_doubles_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, p, n);
+}
+
 }  // namespace
 
 #define PW_CHECK()                                                                              \
@@ -331,7 +342,7 @@ extern "C" int mk_instnorm_fwd_ex(const void* x, const float* weight, const floa
     MK_REQUIRE(phase >= 0 && phase <= 2 && count > 0, "bad phase / count");
     PW_CHECK();
     hipStream_t st = (hipStream_t)stream;
-    if (phase != 2) (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * rows, st);
+    if (phase != 2) zero_doubles(workspace, 2 * rows, st);
     const dim3 g = pw_grid(rows, P);
     const double cnt = (double)count;
 #define LAUNCH(T)                                                                                              \
@@ -370,7 +381,7 @@ extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* st
     MK_REQUIRE(phase >= 0 && phase <= 2 && count > 0, "bad phase / count");
     PW_CHECK();
     hipStream_t st = (hipStream_t)stream;
-    if (phase != 2) (void)hipMemsetAsync(workspace, 0, sizeof(double) * 2 * rows, st);
+    if (phase != 2) zero_doubles(workspace, 2 * rows, st);
     const dim3 g = pw_grid(rows, P);
     const double cnt = (double)count;
 #define LAUNCH(T, G)                                                                                               \
@@ -442,7 +453,7 @@ extern "C" int mk_wmse_fwd(const void* pred, int dtype, const float* tar, const 
     MK_REQUIRE(rows > 0 && rows < 2147483647LL && H > 0 && W > 0 && (W % 8) == 0, "bad sizes (W must be a multiple of 8)");
     MK_REQUIRE(dtype == 0 || dtype == 1, "dtype must be 0 (fp32) or 1 (bf16)");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(loss, 0, sizeof(double), st);
+    zero_doubles(loss, 1, st);
     if (dtype == 0)
         hipLaunchKernelGGL((wmse_kernel<float, false>), dim3((unsigned)rows), dim3(kT), 0, st, (const float*)pred, tar, wrow,
                            loss, (const float*)nullptr, (float*)nullptr, H, W, scale);

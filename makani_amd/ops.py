@@ -736,6 +736,8 @@ def row_sums(t3):
     _need_cuda(t3)
     assert t3.dim() == 3 and t3.is_contiguous()
     b, c, p = t3.shape
+    if os.environ.get("MK_ROWSUM") == "torch":
+        return torch.sum(t3, dim=-1, dtype=torch.float32).view(-1)
     ws = torch.empty(b * c, 2, dtype=torch.float64, device=t3.device)
     _lib.check(_lib.load().mk_instnorm_fwd_ex(t3.data_ptr(), 0, 0, 0, 0, ws.data_ptr(), _pw_dtype(t3), b * c, c, p, p, 0.0, 0,
                                               1, _stream()), "mk_instnorm_fwd_ex")
