@@ -100,6 +100,13 @@ class KernelTimer:
             i = x3.shape[1]
             return float(2 * (o + i) * p * b + 4 * o * i), "byte"
 
+        def pce_work(out, x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False):
+            # every 1x1 convolution of the net sits below the bf16 ridge (intensity M*K/(M+K) <= 256 flop per byte):
+            # HBM is the roof -- X read once, Y written once, plus the optional second input / second output
+            b, k, p = x3.shape
+            rows = k + m + (m if (addend is not None or aux_in is not None) else 0) + (m if want_pre else 0)
+            return float(2 * rows * p * b), "byte"
+
         def rfft_work(out, x, tw, mmax, *s, **kw):
             bc, k, n = x.shape
             return float(k * bc * (x.element_size() * n + 8 * mmax)), "byte"
@@ -120,6 +127,7 @@ class KernelTimer:
         ops.dhconv_dgrad_raw = wrap("dhconv_dgrad", ops.dhconv_dgrad_raw, dh_work)
         ops.dhconv_wgrad_raw = wrap("dhconv_wgrad", ops.dhconv_wgrad_raw, dh_wgrad_work)
         ops.conv1x1_wgrad_raw = wrap("conv1x1_wgrad", ops.conv1x1_wgrad_raw, conv_wgrad_work)
+        ops.pce_gemm = wrap("pce_gemm", ops.pce_gemm, pce_work)
         ops.spec_pack_raw = wrap("spec_pack", ops.spec_pack_raw, layout_work)
         ops.spec_unpack_raw = wrap("spec_unpack", ops.spec_unpack_raw, layout_work)
 

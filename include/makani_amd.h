@@ -253,6 +253,12 @@ int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, con
  * workgroup 0; this copies the 8 x 64 stamps of the last launch to the host. */
 int mk_pce_debug_stamps(unsigned long long* out512);
 
+/* One Adam step (torch.optim.Adam semantics: L2 weight decay folded into the gradient, bias-corrected moments, no
+ * amsgrad) over n contiguous fp32 elements in one streaming pass; `step` is the 1-based step count.  The optimizer
+ * step of the training harness (makani/utils/trainer.py:762-763); complex parameters are stepped as 2 n reals. */
+int mk_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

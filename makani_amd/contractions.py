@@ -9,7 +9,8 @@
   (``mk_dhconv_*``), here wrapped with the layout conversion; ``SpectralConv`` uses the
   packed op directly and skips the conversions.
 * ``diagonal`` complex (unusable at the north-star size): HIP streaming kernels
-  (``mk_diag_*``) on the public layout.  The ``_real`` variants: torch einsum on the device.
+  (``mk_diag_*``) on the public layout.  The ``_real`` variants (real weight on (re, im) pairs): the same kernels with
+  the weight promoted to complex.
 * separable variants: the reference's einsums name an output index ``o`` no operand
   carries and raise ``RuntimeError`` (contractions.py:139-152,169-178); so do these.
 """
@@ -48,11 +49,27 @@ def _contract_sep_dhconv(ac, bc):
     return torch.einsum("bixy,ix->boxy", ac, bc)
 
 
+def _as_hip_complex(a, b):
+    """(complex view of the real-pair input, real weight promoted to complex) when the HIP kernels apply, else None."""
+    if a.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.shape[-1] == 2:
+        return torch.view_as_complex(a.contiguous()), torch.complex(b, torch.zeros_like(b))
+    return None
+
+
 def _contract_diagonal_real(a, b):
+    """``einsum("bixys,ioxy->boxys")`` (contractions.py:155-160): a real weight acting on (re, im) pairs is the complex
+    contraction with a zero imaginary part -- on the device it runs on the same HIP kernels as the complex variant."""
+    hc = _as_hip_complex(a, b)
+    if hc is not None:
+        return torch.view_as_real(_contract_diagonal(*hc)).contiguous()
     return torch.einsum("bixys,ioxy->boxys", a, b).contiguous()
 
 
 def _contract_dhconv_real(a, b):
+    """``einsum("bixys,iox->boxys")`` (contractions.py:163-168), see ``_contract_diagonal_real``."""
+    hc = _as_hip_complex(a, b)
+    if hc is not None:
+        return torch.view_as_real(_contract_dhconv(*hc)).contiguous()
     return torch.einsum("bixys,iox->boxys", a, b).contiguous()
 
 

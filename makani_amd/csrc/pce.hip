@@ -52,7 +52,9 @@ struct PceParams {
     const __hip_bfloat16* aux_in;  // [B][M][P] or null: y *= gelu'(aux_in)   (applied before the addend)
     __hip_bfloat16* aux_out;       // [B][M][P] or null: pre-activation (acc + bias) stored here
     int gelu;                      // y = gelu(acc + bias)
-    int M, Mtot, K, B;             // M: rows of this launch (one pass), Mtot: rows of the whole field (batch stride)
+    int M, K, B;                   // M: output rows of the whole field
+    int npass;                     // passes of 64 TH rows over the same X tile (the second pass finds it in L2)
+    long long img_per_pass;        // bytes of one pass of the weight image
     long long P, tiles_per_b, ntiles;
     unsigned long long* dbg;       // MK_PCE_DBG: s_memtime stamps of workgroup 0 (8 waves x 64 slots), else null
     int exp;                       // MK_PCE_EXP ablations (wrong results): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no X DMA
@@ -375,17 +377,20 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     int si = 0;          // group-in-tile index of the next group to issue
     bool si_next = false;   // ... which belongs to the next tile
     int cx = 0;          // X pieces this wave issued after its last weight pieces
-    auto issue_next_group = [&](int next_tile) {
-        if (si_next && next_tile >= ntiles) return;
-        if (!(p.exp & 4)) issue_group(si, gi & 1);
+    int spass = 0;       // pass the next group to issue belongs to
+    // The work of a workgroup is a sequence of ITEMS (tile, pass): all passes of a tile back to back, then the next tile.
+    auto issue_next_group = [&](bool item_after_exists) {
+        if (si_next && !item_after_exists) return;
+        if (!(p.exp & 4)) issue_group(spass * ngroup_tile + si, gi & 1);
         ++gi;
         if (++si == ngroup_tile) {
             si = 0;
             si_next = true;
+            if (++spass == p.npass) spass = 0;
         }
     };
     if (tile < ntiles) {
-        issue_next_group(tile + gridDim.x);
+        issue_next_group(p.npass > 1 || tile + (int)gridDim.x < ntiles);
         for (int ph = 0; ph < NREG; ++ph) {
             const XTarget t = x_target(tile, ph);
             for (int xg = 0; xg < XG; ++xg) issue_x(t, xg);
@@ -408,8 +413,11 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
 #else
     auto stamp = [&]() {};
 #endif
-    for (; tile < ntiles; tile += gridDim.x) {
-        const int next_tile = tile + gridDim.x;
+    for (; tile < ntiles; tile += gridDim.x)
+    for (int pass = 0; pass < p.npass; ++pass) {
+        // the item after this one: the next pass over the same tile, or the first pass over the next tile
+        const bool last_pass = pass + 1 == p.npass;
+        const int next_tile = last_pass ? tile + (int)gridDim.x : tile;
         const int b = tile / tiles_per_b;
         const long long n0 = (long long)(tile - b * tiles_per_b) * PN;
         f32x16 acc[TH];
@@ -463,7 +471,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                 stamp();   // 4 + 3 gq
                 if (!(p.exp & 32)) block_sync();                // group g complete; everyone is done with group g - 1
                 stamp();   // 5 + 3 gq
-                issue_next_group(next_tile);
+                issue_next_group(next_tile < ntiles);
                 cx = (gq < XG && xt.active) ? issue_x(xt, gq) : 0;
                 if (!(p.exp & 2)) {
                     const uint32_t a = a_lane + (g & 1) * GROUP;
@@ -501,7 +509,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             ea.px_lin = (l & 3) * 8;
             ea.st_lin = stg + ea.row_lin * 64 + (((l & 3) + (ea.row_lin >> 1)) & 3) * 16;
             const long long px0 = n0 + 32 * pg;
-            pce_epilogue<TH, HAS_IN>(p, acc, ea, mh * 32 * TH, ml, (long long)b * p.Mtot * p.P + px0, px0 + ea.px_lin < p.P);
+            pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.M * p.P + px0, px0 + ea.px_lin < p.P);
         } else {
 #pragma unroll
             for (int t = 0; t < TH; ++t) keep_alive(acc[t]);
@@ -634,26 +642,24 @@ extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float
     MK_REQUIRE(bias || zero_bias, "cannot allocate the zero bias");
     const long long tiles_per_b = (P + PN - 1) / PN;
     MK_REQUIRE(tiles_per_b * batch < 2147483647LL, "too many pixel tiles");
-    // M > 64 TH rows: one launch per pass of 64 TH rows (each pass streams X again)
-    const int rows_per_pass = 64 * c.TH;
-    const long long img_per_pass = (long long)c.NPH * c.KSP * 2 * c.TH * 1024;
+    // M > 64 TH rows: passes of 64 TH rows over the same X tile inside one launch
     const char* zeros = (const char*)wimg + pce_image_core_bytes(c);
-    for (int pass = 0; pass < c.npass; ++pass) {
-        const long long roff = (long long)pass * rows_per_pass;
+    {
         PceParams p;
         p.x = (const __hip_bfloat16*)x;
-        p.wimg = (const char*)wimg + pass * img_per_pass;
+        p.wimg = (const char*)wimg;
         p.zeros = zeros;
-        p.y = (__hip_bfloat16*)y + roff * P;
-        p.bias = bias ? bias + roff : zero_bias;
-        p.addend = addend ? (const __hip_bfloat16*)addend + roff * P : nullptr;
-        p.aux_in = aux_in ? (const __hip_bfloat16*)aux_in + roff * P : nullptr;
-        p.aux_out = aux_out ? (__hip_bfloat16*)aux_out + roff * P : nullptr;
+        p.y = (__hip_bfloat16*)y;
+        p.bias = bias ? bias : zero_bias;
+        p.addend = (const __hip_bfloat16*)addend;
+        p.aux_in = (const __hip_bfloat16*)aux_in;
+        p.aux_out = (__hip_bfloat16*)aux_out;
         p.gelu = gelu;
-        p.M = M - (int)roff < rows_per_pass ? M - (int)roff : rows_per_pass;
-        p.Mtot = M;
+        p.M = M;
         p.K = K;
         p.B = batch;
+        p.npass = c.npass;
+        p.img_per_pass = (long long)c.NPH * c.KSP * 2 * c.TH * 1024;
         p.P = P;
         p.tiles_per_b = tiles_per_b;
         p.ntiles = tiles_per_b * batch;

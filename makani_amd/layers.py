@@ -254,7 +254,7 @@ def run_pointwise_chain(mods, x, skip_last_bias=False):
     i = 0
     while i < len(mods):
         m = mods[i]
-        if skip_last_bias and tail_is_noop and i == last_conv and x.is_cuda and m.bias is not None:
+        if skip_last_bias and tail_is_noop and i == last_conv and m.bias is not None:
             x = _ZeroGradBias.apply(m(x, add_bias=False), m.bias)
             i += 1
             continue

@@ -136,6 +136,62 @@ def reduce_shared_gradients(model):
             _coalesced_all_reduce(grads, comm.get_group(name), dist.ReduceOp.SUM)
 
 
+def _mean_all_reduce(t, group):
+    """In-place mean over ``group`` (RCCL has AVG; gloo sums and divides)."""
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.div_(dist.get_world_size(group))
+
+
+def init_gradient_reduction_hooks(model, device_ids=None, output_device=None, bucket_cap_mb=25, broadcast_buffers=True,
+                                  find_unused_parameters=False, gradient_as_bucket_view=True, static_graph=False):
+    """Wrap ``model`` in ``DistributedDataParallel`` over the ``data`` group with a bucket hook that performs every
+    reduction the annotations ask for -- the interface and semantics of ``makani/mpu/mappings.py:30-174``:
+
+    * each gradient: mean over ``data``;
+    * a parameter shared over a model-parallel group (``is_shared_mp``, default ``["model"]``): sum over that group;
+    * complex gradients travel as pairs of reals.
+
+    The hook fires per bucket as backward produces it, so the (RCCL) reductions of early buckets run under the rest of
+    the backward pass; ``reduce_shared_gradients`` is the same arithmetic issued after backward, without the wrapper.
+    Every parameter must receive a gradient each step (``find_unused_parameters=False``, as in the reference's trainer):
+    the fused paths of this package hand out exact zeros where a gradient vanishes identically instead of ``None``.
+    """
+    if not dist.is_initialized():
+        return model
+    from torch.nn.parallel import DistributedDataParallel
+    for p in model.parameters():
+        if not hasattr(p, "is_shared_mp"):
+            p.is_shared_mp = ["model"]
+    ddp = DistributedDataParallel(model, device_ids=device_ids, output_device=output_device, bucket_cap_mb=bucket_cap_mb,
+                                  broadcast_buffers=False if comm.get_size("model") > 1 else broadcast_buffers,
+                                  find_unused_parameters=find_unused_parameters,
+                                  gradient_as_bucket_view=gradient_as_bucket_view, static_graph=static_graph,
+                                  process_group=comm.get_group("data"))
+    model_groups = [n for n in comm.get_names() if n != "data" and comm.get_size(n) > 1]
+
+    def hook(state, bucket):
+        buf = bucket.buffer()
+        flat = torch.view_as_real(buf) if buf.is_complex() else buf
+        if comm.get_size("data") > 1:
+            _mean_all_reduce(flat, comm.get_group("data"))
+        if model_groups:
+            params = bucket.parameters()
+            grads = bucket.gradients()          # views into the bucket, one per parameter
+            for name in model_groups:
+                shared = [g for p, g in zip(params, grads) if name in p.is_shared_mp]
+                if shared:
+                    _coalesced_all_reduce(shared, comm.get_group(name), dist.ReduceOp.SUM)
+        fut = torch.futures.Future()
+        fut.set_result(buf)
+        return fut
+
+    ddp.register_comm_hook(state=None, hook=hook)
+    return ddp
+
+
 def sync_params(model):
     """Broadcast shared parameters from each group's root (mpu/helpers.py:59-103, simplified)."""
     if not dist.is_initialized() or comm.get_world_size() == 1:

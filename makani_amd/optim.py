@@ -1,27 +1,51 @@
 """Single-pass Adam over the model's parameters, complex ones included.
 
 The reference patches torch's Adam for complex parameters (``makani/third_party/torch``) and
-steps outside the captured graph (``makani/utils/trainer.py:762-763``); torch >= 2.1 handles
-complex parameters natively but only in the multi-pass ``foreach`` form (7 HBM passes over the
-2.3 GB of spectral weights).  Here every parameter is handed to ``torch.optim.Adam(fused=True)``
-as a real leaf view sharing its storage (complex64 -> ``view_as_real``), which is the same
-arithmetic (Adam treats a complex number as two reals) in one multi-tensor kernel.
+steps outside the captured graph (``makani/utils/trainer.py:762-763``).  Adam treats a complex
+number as two reals, so every parameter is stepped through a real view of its storage
+(complex64 -> ``view_as_real``):
+
+* large dense tensors (the spectral weights: 283 M of the net's 289 M parameters) by
+  ``mk_adam_step`` -- one HIP streaming pass per tensor over its storage in memory order;
+* the many small ones by ``torch.optim.Adam(fused=True)`` in one multi-tensor launch.
 """
 import torch
+
+from . import _lib
+
+_BIG = 1 << 20      # elements: below this the per-tensor launch is not worth it
+
+
+def _flat_storage_view(t):
+    """1-D view over a dense tensor's elements in memory order (works for permuted-contiguous layouts), or None."""
+    if t.is_contiguous():
+        return t.view(-1)
+    order = sorted(range(t.dim()), key=lambda d: -t.stride(d))
+    tp = t.permute(order)
+    return tp.reshape(-1) if tp.is_contiguous() else None
 
 
 class FusedAdam:
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.params = [p for p in params if p.requires_grad]
-        self.views = []
+        self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+        self.views, self._small, self._big = [], [], []
         for p in self.params:
             v = (torch.view_as_real(p.data) if p.is_complex() else p.data).detach()
             self.views.append(v)
-        self.opt = torch.optim.Adam(self.views, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, fused=True)
+            flat = _flat_storage_view(v) if (v.is_cuda and v.dtype == torch.float32 and v.numel() >= _BIG) else None
+            if flat is not None and flat.data_ptr() % 16 == 0:
+                self._big.append({"p": p, "flat": flat, "m": torch.zeros_like(flat), "v": torch.zeros_like(flat), "step": 0})
+            else:
+                self._small.append((p, v))
+        self.opt = None
+        if self._small:
+            self.opt = torch.optim.Adam([v for _, v in self._small], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                        fused=all(v.is_cuda for _, v in self._small))
 
     @property
     def param_groups(self):
-        return self.opt.param_groups
+        return self.opt.param_groups if self.opt is not None else [dict(self.defaults)]
 
     def zero_grad(self, set_to_none=True):
         for p, v in zip(self.params, self.views):
@@ -31,21 +55,46 @@ class FusedAdam:
             elif p.grad is not None:
                 p.grad.zero_()
 
+    @staticmethod
+    def _grad_like_param(p):
+        g = p.grad
+        if g is not None and g.stride() != p.stride():      # the kernels walk storage linearly: layouts must agree
+            g2 = torch.empty_like(p.data)                    # preserve_format -> the parameter's strides
+            g2.copy_(g)
+            g = g2
+        return g
+
     def step(self):
-        for p, v in zip(self.params, self.views):
-            g = p.grad
+        for p, v in self._small:
+            g = self._grad_like_param(p)
+            v.grad = None if g is None else (torch.view_as_real(g) if g.is_complex() else g)
+        if self.opt is not None:
+            self.opt.step()
+        if not self._big:
+            return
+        lib = _lib.load()
+        hp = self.param_groups[0] if self.opt is not None else self.defaults
+        lr, (b1, b2), eps, wd = hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"]
+        stream = torch.cuda.current_stream().cuda_stream
+        for st in self._big:
+            g = self._grad_like_param(st["p"])
             if g is None:
-                v.grad = None
                 continue
-            if g.stride() != p.stride():      # the fused kernel walks storage linearly: layouts must agree
-                g2 = torch.empty_like(p.data)  # preserve_format -> the parameter's strides
-                g2.copy_(g)
-                g = g2
-            v.grad = torch.view_as_real(g) if g.is_complex() else g
-        self.opt.step()
+            gf = _flat_storage_view(torch.view_as_real(g) if g.is_complex() else g)
+            assert gf is not None and gf.dtype == torch.float32 and gf.numel() == st["flat"].numel()
+            st["step"] += 1
+            _lib.check(lib.mk_adam_step(st["flat"].data_ptr(), gf.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(),
+                                        gf.numel(), float(lr), float(b1), float(b2), float(eps), float(wd), st["step"], stream),
+                       "mk_adam_step")
 
     def state_dict(self):
-        return self.opt.state_dict()
+        return {"small": None if self.opt is None else self.opt.state_dict(),
+                "big": [{"m": st["m"], "v": st["v"], "step": st["step"]} for st in self._big]}
 
     def load_state_dict(self, sd):
-        self.opt.load_state_dict(sd)
+        if self.opt is not None and sd.get("small") is not None:
+            self.opt.load_state_dict(sd["small"])
+        for st, src in zip(self._big, sd.get("big", [])):
+            st["m"].copy_(src["m"])
+            st["v"].copy_(src["v"])
+            st["step"] = int(src["step"])

@@ -284,8 +284,9 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                  inp_chans=2, out_chans=2, embed_dim=32, num_layers=4, use_mlp=True, mlp_ratio=2.0,
                  encoder_ratio=1, decoder_ratio=1, activation_function="gelu", encoder_layers=1,
                  normalization_layer="instance_norm", max_modes=None, hard_thresholding_fraction=1.0,
-                 big_skip=True, separable=False, bias=False, **kwargs):
+                 big_skip=True, separable=False, bias=False, repeat_layers=1, pos_embed="none", **kwargs):
         super().__init__()
+        self.repeat_layers = repeat_layers
         self.inp_shape, self.out_shape = inp_shape, out_shape
         self.inp_chans, self.out_chans, self.embed_dim = inp_chans, out_chans, embed_dim
         self.big_skip = big_skip
@@ -328,6 +329,20 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         if big_skip:
             self.residual_transform = nn.Conv2d(inp_chans, out_chans, 1, bias=False)
             nn.init.normal_(self.residual_transform.weight, mean=0.0, std=math.sqrt(0.5 / inp_chans))
+        # position embedding (sfnonet.py:469-501): a grid field, or (re, im) spectral coefficients synthesised each call
+        if pos_embed == "direct":
+            self.pos_embed = nn.Parameter(torch.zeros(1, embed_dim, *inp_shape))
+            self.pos_embed.type = "direct"
+            nn.init.trunc_normal_(self.pos_embed, std=0.02)
+        elif pos_embed == "frequency":
+            rc = nn.Parameter(torch.tril(torch.randn(1, embed_dim, modes_lat, modes_lon), diagonal=0))
+            cc = nn.Parameter(torch.tril(torch.randn(1, embed_dim, modes_lat, modes_lon - 1), diagonal=-1))
+            nn.init.trunc_normal_(rc, std=0.02)
+            nn.init.trunc_normal_(cc, std=0.02)
+            self.pos_embed = nn.ParameterList([rc, cc])
+            self.pos_embed.type = "frequency"
+        elif pos_embed not in ("none", "None", None):
+            raise ValueError("Unknown position embedding type")
 
     def forward(self, x):
         if self.big_skip:
@@ -336,8 +351,16 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             else:
                 residual = x
         x = self.encoder(x)
-        for blk in self.blocks:
-            x = blk(x)
+        if hasattr(self, "pos_embed"):                      # sfnonet.py:606-618
+            if self.pos_embed.type == "frequency":
+                pe = torch.stack([self.pos_embed[0], nn.functional.pad(self.pos_embed[1], (1, 0), "constant", 0)], dim=-1)
+                pe = self.itrans_up(torch.view_as_complex(pe))
+            else:
+                pe = self.pos_embed
+            x = x + pe
+        for _ in range(self.repeat_layers):                 # sfnonet.py:574-585
+            for blk in self.blocks:
+                x = blk(x)
         x = self.decoder(x)
         if self.big_skip:
             x = x + self.residual_transform(residual)

@@ -273,6 +273,65 @@ def _body_net(rank, world):
         assert err < 5e-5, (n, err)
 
 
+def _body_ddp(rank, world):
+    """The reference's wrapper (mpu/mappings.py:30-174 semantics): DistributedDataParallel(find_unused_parameters=False)
+    with the gradient-reduction hook, two optimizer steps; the reduced gradients equal reduce_shared_gradients' ones."""
+    import copy
+    from makani_amd import comm, mappings
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    torch.manual_seed(333)
+    kw = dict(inp_shape=(17, 32), out_shape=(17, 32), scale_factor=2, inp_chans=3, out_chans=2, embed_dim=6, num_layers=2)
+    net = SphericalFourierNeuralOperatorNet(**kw)
+    mappings.sync_params(net)
+    twin = copy.deepcopy(net)
+    for (n, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):   # deepcopy drops the annotations
+        for a in ("is_shared_mp", "sharded_dims_mp"):
+            if hasattr(p, a):
+                setattr(q, a, getattr(p, a))
+    ddp = mappings.init_gradient_reduction_hooks(net, device_ids=None, output_device=None, find_unused_parameters=False)
+    opt = torch.optim.SGD(ddp.parameters(), lr=1e-2)
+    lat = net.inp_shape_loc[0]
+    torch.manual_seed(1000 + comm.get_rank("data"))          # different samples per data rank
+    for step in range(2):                                       # step 2 raises if a parameter got no gradient in step 1
+        x, t = torch.randn(2, 3, lat, 32), torch.randn(2, 2, lat, 32)
+        opt.zero_grad(set_to_none=True)
+        ((ddp(x) - t) ** 2).sum().backward()
+        if step == 0:
+            twin.zero_grad(set_to_none=True)
+            ((twin(x) - t) ** 2).sum().backward()
+            mappings.reduce_shared_gradients(twin)
+            for (n, p), (_, q) in zip(net.named_parameters(), twin.named_parameters()):
+                assert p.grad is not None, n
+                assert _rel(torch.view_as_real(p.grad) if p.grad.is_complex() else p.grad,
+                            torch.view_as_real(q.grad) if q.grad.is_complex() else q.grad) < 1e-6 or q.grad.abs().max() < 1e-12, n
+        opt.step()
+
+
+def _body_sht721(rank, world):
+    """BASELINE.json configs[3] / [4] shard shapes on the production grid: 721 latitudes over h = 4 -> [181, 181, 181,
+    178], over h = 8 -> [91] * 7 + [84]; 240 degrees evenly; analysis + synthesis against the serial oracle."""
+    from makani_amd import comm
+    from makani_amd.distributed import DistributedRealSHT, DistributedInverseRealSHT, compute_split_shapes
+    from oracle import spectral as osp
+    torch.manual_seed(333)
+    h = comm.get_size("h")
+    nlat, nlon, lmax, mmax, B, C = 721, 1440, 240, 241, 1, h
+    f = DistributedRealSHT(nlat, nlon, lmax, mmax, "equiangular")
+    fi = DistributedInverseRealSHT(nlat, nlon, lmax, mmax, "equiangular")
+    want = {4: [181, 181, 181, 178], 8: [91] * 7 + [84]}[h]
+    assert f.lat_shapes == want and fi.lat_shapes == want and f.l_shapes == [lmax // h] * h
+    assert compute_split_shapes(C, h) == [1] * h
+    fo, fio = osp.TorchRealSHT(nlat, nlon, lmax, mmax, "equiangular"), osp.TorchInverseRealSHT(nlat, nlon, lmax, mmax, "equiangular")
+    xg = torch.randn(B, C, nlat, nlon)
+    co = fo(xg)
+    cl = f(_shard(xg, 2, "h"))
+    assert cl.shape == (B, C, lmax // h, mmax)
+    assert _rel(_gather(cl, 2, "h"), co) < TOL
+    yl = fi(_shard(co, 2, "h"))
+    assert yl.shape == (B, C, want[comm.get_rank("h")], nlon)
+    assert _rel(_gather(yl, 2, "h"), fio(co)) < TOL
+
+
 # ------------------------------------------------------------------ launcher
 def _run(world, hsize, wsize, what):
     ctx = mp.get_context("spawn")
@@ -300,3 +359,16 @@ def test_h2_w2(what):
 
 def test_data_parallel_times_h():
     _run(4, 2, 1, "groups")
+
+
+def test_ddp_wrapper_data_parallel():
+    _run(2, 1, 1, "ddp")
+
+
+def test_ddp_wrapper_model_parallel():
+    _run(2, 2, 1, "ddp")
+
+
+@pytest.mark.parametrize("h", [4, 8])
+def test_production_grid_shards(h):
+    _run(h, h, 1, "sht721")

@@ -474,3 +474,28 @@ def test_fft_peer_major_layout(dev, nlat, nlon, mmax, B, C, cpp):
     assert torch.equal(y0, y1)
     yb = ops.irfft_pm_raw(b, tw, nlon, 1.0, 1.0, 1.0, C, cpp, torch.bfloat16)
     assert torch.equal(yb, ops.irfft_raw(a, tw, nlon, 1.0, 1.0, 1.0, torch.bfloat16, kmajor=True))
+
+
+def test_adam_step_matches_torch(dev):
+    """mk_adam_step (one streaming pass, makani_amd/optim.py) against torch.optim.Adam over three steps, on a real
+    tensor, a complex one and a permuted-contiguous one (the dhconv weight layout), with weight decay."""
+    from makani_amd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(1100, 1001), (96, 96, 120)]
+    ps = [torch.randn(*shapes[0], device=dev), torch.randn(*shapes[1], dtype=torch.complex64, device=dev),
+          torch.randn(120, 96, 96, dtype=torch.complex64, device=dev).permute(1, 2, 0), torch.randn(7, 5, device=dev)]
+    ps = [torch.nn.Parameter(p.clone() if p.is_contiguous() else p) for p in ps]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FusedAdam(ps, lr=1e-2, weight_decay=0.1)
+    assert len(opt._big) == 3 and len(opt._small) == 1
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=0.1)
+    for _ in range(3):
+        for p, r in zip(ps, ref):
+            g = torch.randn_like(r)
+            r.grad = g.clone()
+            p.grad = g.clone() if p.is_contiguous() else g.permute(2, 0, 1).contiguous().permute(1, 2, 0)
+        opt.step()
+        ropt.step()
+    for p, r in zip(ps, ref):
+        a, b = torch.view_as_real(p.detach()) if p.is_complex() else p.detach(), torch.view_as_real(r.detach()) if r.is_complex() else r.detach()
+        assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-6

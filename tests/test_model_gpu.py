@@ -120,25 +120,6 @@ NET_CASES = [
 ]
 
 
-def test_sfno_full_config_forward_vs_oracle(dev):
-    """BASELINE.json configs[2]: sfno_linear_73chq_sc3_layers8_edim384 full forward, batch 1, fp32, against the CPU
-    oracle with identical (random-init) weights: 289 M parameters, 73 x 721 x 1440 in and out."""
-    import bench
-    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
-    from oracle import spectral as osp
-    torch.manual_seed(333)
-    ref = osp.SphericalFourierNeuralOperatorNet(**bench.CONFIG)
-    net = SphericalFourierNeuralOperatorNet(**bench.CONFIG)
-    net.load_state_dict(ref.state_dict(), strict=True)
-    net = net.to(dev)
-    x = torch.randn(1, 73, 721, 1440)
-    with torch.no_grad():
-        y = net(x.to(dev))
-        yo = ref(x)
-    assert tuple(y.shape) == (1, 73, 721, 1440)
-    assert rel(y, yo) < TOL
-
-
 @pytest.mark.parametrize("kw", NET_CASES)
 def test_sfno_net_vs_oracle(dev, kw):
     from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
@@ -165,6 +146,33 @@ def test_sfno_net_vs_oracle(dev, kw):
     # a bias in front of an instance norm has an identically zero gradient: the fused path skips that add and hands the
     # parameter an exact zero (every parameter gets a gradient: DDP with find_unused_parameters=False relies on it)
     assert all(p.grad is not None for p in net.parameters())
+    errs = {n: rel(p.grad, po[n].grad, floor=1e-1 * scale) for n, p in net.named_parameters()}
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 5 * TOL, (worst, errs[worst])
+
+
+@pytest.mark.parametrize("extra", [dict(pos_embed="direct"), dict(pos_embed="frequency"), dict(repeat_layers=2),
+                                   dict(checkpointing=3), dict(checkpointing=1, pos_embed="frequency", repeat_layers=2)])
+def test_sfno_optional_branches_vs_oracle(dev, extra):
+    """pos_embed (sfnonet.py:469-501, 606-618), repeat_layers and the activation-checkpointing levels (574-585):
+    forward, input gradient and every parameter gradient against the oracle."""
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from oracle import spectral as osp
+    torch.manual_seed(21)
+    kw = dict(inp_shape=(33, 64), out_shape=(33, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=8, num_layers=2)
+    okw = {k: v for k, v in extra.items() if k != "checkpointing"}
+    ref = osp.SphericalFourierNeuralOperatorNet(**kw, **okw)
+    net = SphericalFourierNeuralOperatorNet(**kw, **extra).to(dev)
+    net.load_state_dict(ref.state_dict(), strict=True)
+    x, tar = torch.randn(2, 4, 33, 64), torch.randn(2, 3, 33, 64)
+    xd, xo = x.to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    y, yo = net(xd), ref(xo)
+    assert rel(y, yo) < TOL
+    ((y - tar.to(dev)) ** 2).mean().backward()
+    ((yo - tar) ** 2).mean().backward()
+    assert rel(xd.grad, xo.grad) < 5 * TOL
+    po = dict(ref.named_parameters())
+    scale = float(np.median([torch.linalg.norm(_f64(p.grad)).item() for p in po.values()]))
     errs = {n: rel(p.grad, po[n].grad, floor=1e-1 * scale) for n, p in net.named_parameters()}
     worst = max(errs, key=errs.get)
     assert errs[worst] < 5 * TOL, (worst, errs[worst])
