@@ -253,6 +253,22 @@ def cpu_baseline():
             "parts_s": {k: round(v, 3) for k, v in parts.items()}}
 
 
+def cpu_full_step():
+    """One complete oracle forward + backward of the benchmark configuration (B = 1, fp32) on the host cores: the check of
+    the slice extrapolation above (`--full-cpu-baseline`)."""
+    from oracle import spectral as osp
+    torch.set_num_threads(_host_cores())
+    torch.manual_seed(0)
+    kw = {k: v for k, v in CONFIG.items() if k not in ("spectral_transform", "filter_type", "pos_embed")}
+    net = osp.SphericalFourierNeuralOperatorNet(**kw)
+    x, tar = torch.randn(1, 73, 721, 1440), torch.randn(1, 73, 721, 1440)
+    t0 = time.time()
+    ((net(x) - tar) ** 2).mean().backward()
+    dt = time.time() - t0
+    print(f"[cpu_baseline] full oracle step: {dt:.1f} s", file=sys.stderr, flush=True)
+    return round(dt, 2)
+
+
 # ----------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -261,6 +277,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--full-cpu-baseline", action="store_true",
+                    help="also run ONE complete oracle forward+backward of the full configuration on the host cores "
+                         "(minutes, tens of GB of RAM) and report it next to the slice extrapolation")
     ap.add_argument("--graph", action="store_true",
                     help="capture forward+loss+backward in a HIP graph and replay it (reference: trainer.py:84-152, "
                          "optimizer step outside the graph); kernel timing then comes from an eager pre-pass")
@@ -277,6 +296,7 @@ def main():
     # rehearsal hooks (one-GPU box): MK_BENCH_BACKEND=gloo MK_BENCH_ONE_DEVICE=1 run every rank on cuda:0 over gloo,
     # which exercises this script's whole N > 1 path except the RCCL wire.  The driver's runs use neither.
     if world > 1:
+        # a collective that stalls (MK_COLLECTIVE_TIMEOUT, default 300 s) aborts the rank with a non-zero exit code
         comm.init(model_parallel_sizes=[world, 1, 1, 1], model_parallel_names=["h", "w", "fin", "fout"],
                   backend=os.environ.get("MK_BENCH_BACKEND", "nccl"))
     rank = comm.get_world_rank()
@@ -432,6 +452,9 @@ def main():
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
+            if args.full_cpu_baseline:
+                cpu["full_step_s"] = cpu_full_step()
+                cpu["extrapolation_over_full"] = round((1.0 / cpu["value"]) / cpu["full_step_s"], 3)
         line = {
             "metric": "SFNO fwd+bwd samples/sec, 73ch 721x1440",
             "value": round(B * args.steps / elapsed, 4), "unit": "samples/s", "n_gpus": world, "steps": args.steps,

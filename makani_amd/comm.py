@@ -137,11 +137,16 @@ def init(model_parallel_sizes=(1, 1, 1, 1), model_parallel_names=("h", "w", "fin
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        # A collective that does not complete within MK_COLLECTIVE_TIMEOUT seconds (default 300) makes the watchdog
+        # abort the process with a non-zero exit code instead of hanging it (a rank that died, a mismatched sequence).
+        import datetime
+        timeout = datetime.timedelta(seconds=int(os.environ.get("MK_COLLECTIVE_TIMEOUT", "300")))
         if backend == "nccl":
+            os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")     # tear the process down on a timeout
             torch.cuda.set_device(local_rank)
-            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend=backend, device_id=torch.device("cuda", local_rank), timeout=timeout)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, timeout=timeout)
     world_size, rank = dist.get_world_size(), dist.get_rank()
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 

@@ -14,6 +14,7 @@
 #include "../../include/makani_amd.h"
 
 #include <hip/hip_bf16.h>
+#include <cstdint>
 #include <cstdlib>
 
 namespace {
@@ -455,6 +456,7 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
     MK_REQUIRE(gy && x && gw, "null pointer");
     MK_REQUIRE(batch > 0 && cout > 0 && cin > 0 && P > 0, "bad sizes");
     MK_REQUIRE((P % 8) == 0, "P = H*W must be a multiple of 8 (16-byte row alignment)");
+    MK_REQUIRE((((uintptr_t)gy | (uintptr_t)x) & 15) == 0, "gy and x must be 16-byte aligned (the tiles are read as uint4)");
     WgradParams p;
     p.gy = (const __hip_bfloat16*)gy;
     p.x = (const __hip_bfloat16*)x;
@@ -587,6 +589,8 @@ extern "C" int mk_conv1x1_fwd(const void* a, const void* x, const void* addend, 
     MK_REQUIRE(a && x && y, "null pointer");
     MK_REQUIRE(batch > 0 && M > 0 && K > 0 && P > 0, "bad sizes");
     MK_REQUIRE((P % 8) == 0 && (K % 8) == 0, "K and P = H*W must be multiples of 8 (16-byte row alignment)");
+    MK_REQUIRE((((uintptr_t)a | (uintptr_t)x | (uintptr_t)y | (uintptr_t)addend) & 15) == 0,
+               "a, x, y and addend must be 16-byte aligned (the tiles are read as uint4)");
     NnParams p;
     p.a = (const __hip_bfloat16*)a;
     p.x = (const __hip_bfloat16*)x;

@@ -152,12 +152,15 @@ def _gemm_mode(mode):
 
 
 def legendre_x3_image(table, nlat, inverse):
-    """Pre-split tile image of a device fp32 Legendre table (built once, cached on the tensor object)."""
+    """Pre-split tile image of a device fp32 Legendre table (built once, cached on the tensor object).
+
+    The image is built on whatever stream needs it first; the cache entry carries the event recorded behind the
+    build, and a hit from another stream waits for it (two micro-batch streams start cold together, pipeline.py)."""
     _need_cuda(table)
     cache = table.__dict__.setdefault("_mk_x3", {})
     key = (int(nlat), int(bool(inverse)))
-    img = cache.get(key)
-    if img is None:
+    entry = cache.get(key)
+    if entry is None:
         lib = _lib.load()
         mg, lmax, kp = table.shape
         assert kp == legendre_kpad(nlat) and table.is_contiguous() and table.dtype == torch.float32
@@ -165,8 +168,16 @@ def legendre_x3_image(table, nlat, inverse):
         img = torch.empty(nbytes, dtype=torch.uint8, device=table.device)
         _lib.check(lib.mk_legendre_x3_split(table.data_ptr(), img.data_ptr(), nlat, lmax, mg, key[1], _stream()),
                    "mk_legendre_x3_split")
-        cache[key] = img
-    return img
+        ev = torch.cuda.Event()
+        ev.record()
+        cache[key] = entry = [img, ev]
+        return img
+    if entry[1] is not None:
+        if entry[1].query():
+            entry[1] = None                     # built and finished: nothing to order any more
+        else:
+            torch.cuda.current_stream().wait_event(entry[1])
+    return entry[0]
 
 
 def legendre_fwd_raw(xf, table, lmax, m_off=0, mode=None, kmajor=False):

@@ -499,3 +499,33 @@ def test_adam_step_matches_torch(dev):
     for p, r in zip(ps, ref):
         a, b = torch.view_as_real(p.detach()) if p.is_complex() else p.detach(), torch.view_as_real(r.detach()) if r.is_complex() else r.detach()
         assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
+
+
+def test_conv_kernels_reject_misaligned_and_odd_sizes(dev):
+    """The bf16 1x1-conv kernels read 16-byte vectors: odd pixel counts and offset views whose base is not 16-byte
+    aligned must come back as an error from the C ABI (never as a device fault), and aligned offset views must work.
+    (Round-1 note: the one GPU memory fault on record, gpurun_out/tun.log, happened while torch's TunableOp was trying
+    vendor GEMM solutions on the first transposed 73-channel shape -- 146-byte rows; the in-tree kernels were not running.)"""
+    from makani_amd import ops, _lib
+    lib = _lib.load()
+    torch.manual_seed(0)
+    O, I, P = 40, 24, 264
+    gy = torch.randn(1, O, P + 8, device=dev).bfloat16()
+    x = torch.randn(1, I, P + 8, device=dev).bfloat16()
+    gw = torch.zeros(O, I, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+    # odd pixel count
+    assert lib.mk_conv1x1_wgrad(gy.data_ptr(), x.data_ptr(), gw.data_ptr(), 1, O, I, P + 3, st) != 0
+    # base pointer off by one element (2 bytes)
+    assert lib.mk_conv1x1_wgrad(gy.data_ptr() + 2, x.data_ptr(), gw.data_ptr(), 1, O, I, P, st) != 0
+    assert lib.mk_pce_gemm(x.data_ptr() + 2, x.data_ptr(), gy.data_ptr(), None, None, None, None, 0, 1, O, I, P, st) != 0
+    # an aligned offset view (8 elements = 16 bytes in) is fine and exact
+    gyv = gy.view(-1)[8:8 + O * P].view(1, O, P)
+    xv = x.view(-1)[8:8 + I * P].view(1, I, P)
+    assert gyv.data_ptr() % 16 == 0 and gyv.is_contiguous()
+    got = ops.conv1x1_wgrad_raw(gyv, xv)
+    want = gyv[0].double() @ xv[0].double().t()
+    assert rel(got.cpu().numpy(), want.cpu().numpy()) < 1e-5
+    w = (torch.randn(O, I, device=dev) / I ** 0.5)
+    y = ops.pce_gemm(xv, ops.pce_pack(w), O)
+    assert rel(y.float().cpu().numpy(), (w.bfloat16().double() @ xv[0].double()).unsqueeze(0).cpu().numpy()) < 3e-3
