@@ -238,17 +238,19 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
             lds_write_b64<0>(quad_addr(g), q);
         }
     };
+    // all bias values up front: a load issued between the stores of two tiles would be waited for with vmcnt(0), i.e. behind
+    // the round trip of every store queued before it
+    float bias_t[TH];
+#pragma unroll
+    for (int t = 0; t < TH; ++t) bias_t[t] = p.bias[m_first + 32 * t + m_local];   // always there (zeros if the layer has none)
     if constexpr (has_in) fetch(0, pf[0]);
 #pragma unroll
     for (int t = 0; t < TH; ++t) {
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[t][r];
-        {
-            const float bv = p.bias[m_first + 32 * t + m_local];    // always there (zeros if the layer has none), padded to 64 TH
 #pragma unroll
-            for (int r = 0; r < 16; ++r) v[r] += bv;
-        }
+        for (int r = 0; r < 16; ++r) v[r] += bias_t[t];
         if (p.aux_out) {
             stage(v);
             flush(reinterpret_cast<unsigned short*>(p.aux_out), t);
@@ -283,26 +285,36 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
     }
 }
 
-// KSP: k16 steps per K phase (2, 6 or 12: phases of <= 192 k rows), NPH: phases (1, 2, 4), TH: 32-row tiles per wave.
+// KSP: k16 steps per K phase (2, 4 or 8: phases of <= 128 k rows), NPH: phases (1, 2, 3, 6), TH: 32-row tiles per wave.
 //
 // Schedule of one workgroup (all 8 waves alike).  The weight stream is cut into GROUPS of two k16 steps (24 KB at
-// TH = 6) and double-buffered; one iteration = { wait for my pieces of group g, barrier, put group g + 1 and two
-// pieces of a coming X region in flight, 12 fragment reads + 12 MFMAs per wave on group g }.  vmcnt retires in issue
-// order, so a wave always issues its weight pieces BEFORE its X pieces: the wait for the weights is then
-// "all but my youngest cx operations", which leaves the X pieces (HBM latency) in flight for another iteration.
-// X pieces go out in the first groups of a phase only, so the vmcnt(0) waits of its later groups have retired them
-// long before the region is read (two phases later) and before the epilogue's stores are queued.
+// TH = 6) that rotate through THREE LDS buffers; fragments are read one half-step ahead of the MFMAs that use them:
+//
+//   iteration g:   wait for my pieces of group g + 1 (vmcnt, see below); barrier
+//                  DMA: group g + 2 -> the buffer group g - 1 lived in; up to two pieces of a coming X region
+//                  ds_read step 1 of group g -> af1      | 6 MFMAs on af0 (step 0 of group g, read in iteration g - 1)
+//                  ds_read step 0 of group g + 1 -> af0  | 6 MFMAs on af1
+//
+// so the LDS latency, the DMA issue and the barrier skew of a wave sit under MFMAs (its own or those of the other wave
+// of its SIMD) instead of in front of them -- the earlier two-buffer schedule read a group's fragments only after the
+// barrier that published it and ran 2,000 cycles per 768 cycles of matrix work.
+// vmcnt retires in issue order, so a wave issues its weight pieces BEFORE its X pieces: the wait for the weights is then
+// "all but my youngest cx operations", which leaves the X pieces (HBM latency) in flight for another iteration.  X pieces
+// go out in the first half of a phase only, so the vmcnt(0) waits of its later groups have retired them long before the
+// region is read (two phases later) and before the epilogue's stores are queued.
 template <int KSP, int NPH, int TH, bool HAS_IN>
 __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     constexpr int SLOT = 2 * TH * 1024;          // 2 TH row tiles x one k16 step
     constexpr int GS = 2;                        // k16 steps per group
     constexpr int GROUP = GS * SLOT;
+    constexpr int NBUF = 3;
     constexpr int NG = KSP / GS;                 // groups per phase
     constexpr int NPG = GS * 2 * TH;             // 1 KB weight pieces per group, piece q issued by wave q % 8
-    constexpr int NREG = NPH > 1 ? 2 : 1;        // X regions in LDS: phase ph lives in region ph & 1
+    constexpr int NREG = NPH > 1 ? 2 : 1;        // X regions in LDS: the q-th phase a workgroup runs lives in region q & 1
     constexpr int REG_BYTES = 16 * KSP * XROW;   // one region = the k rows of one phase x 128 px
     constexpr int NXP = 4 * KSP;                 // 1 KB pieces per X region (4 k rows each)
     constexpr int XG = (NXP + 15) / 16;          // groups of a phase that carry X pieces (2 per wave and group)
+    static_assert(XG <= NG, "X pieces must fit the groups of a phase");
     extern __shared__ __attribute__((aligned(1024))) char lds[];
     char* XS = lds;
     char* WB = lds + NREG * REG_BYTES;
@@ -325,8 +337,8 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     // ---- DMA issue: every wave-instruction is issued with all lanes (lanes outside the field or past K fetch from a
     //      zero block behind the weight image), so the vmcnt bookkeeping is static and LDS never keeps stale rows ----
     const char* w_lane = p.wimg + lane * 16 + wave * 1024;
-    auto issue_group = [&](int group_in_tile, int buf) {
-        const char* src = w_lane + (long long)group_in_tile * GROUP;
+    auto issue_group = [&](int group_in_image, int buf) {
+        const char* src = w_lane + (long long)group_in_image * GROUP;
         char* dst = WB + buf * GROUP + wave * 1024;
 #pragma unroll
         for (int q = 0; q < (NPG + 7) / 8; ++q)
@@ -337,11 +349,11 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     struct XTarget {
         const __hip_bfloat16* src;    // this lane's source of piece 0 (k row = lane >> 4)
         char* dst;                    // LDS region
-        int krow0;                    // first k row of the phase
+        int krow0;                    // this lane's k row in piece 0
         bool lane_ok;                 // this lane's pixels are inside the field
         bool active;
     };
-    auto x_target = [&](int tile, int phase) {
+    auto x_target = [&](int tile, int phase, int region) {
         XTarget t;
         const int b = tile / tiles_per_b;
         const int l = opaque_lane();
@@ -349,7 +361,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         const long long n = (long long)(tile - b * tiles_per_b) * PN + x_chunk * 8;
         t.krow0 = phase * 16 * KSP + (l >> 4);
         t.src = p.x + ((long long)b * p.K + t.krow0) * p.P + n;
-        t.dst = XS + (phase & (NREG - 1)) * REG_BYTES;
+        t.dst = XS + region * REG_BYTES;
         t.lane_ok = n < p.P;
         t.active = true;
         return t;
@@ -371,17 +383,18 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     };
 
     int tile = blockIdx.x;
-    int g = 0;           // running group counter: group g lives in ring buffer g & 1
+    int g = 0;           // running group counter: group g lives in ring buffer g % 3
     int gi = 0;          // groups issued so far
     int landed = 0;      // groups known to have landed (drained before the last epilogue)
-    int si = 0;          // group-in-tile index of the next group to issue
-    bool si_next = false;   // ... which belongs to the next tile
-    int cx = 0;          // X pieces this wave issued after its last weight pieces
+    int si = 0;          // group-in-item index of the next group to issue
     int spass = 0;       // pass the next group to issue belongs to
+    bool si_next = false;   // ... which belongs to the item after the current one
+    int cx = 0;          // X pieces this wave issued after its last weight pieces
+    int q = 0;           // running phase counter: phase q lives in X region q & (NREG - 1)
     // The work of a workgroup is a sequence of ITEMS (tile, pass): all passes of a tile back to back, then the next tile.
     auto issue_next_group = [&](bool item_after_exists) {
         if (si_next && !item_after_exists) return;
-        if (!(p.exp & 4)) issue_group(spass * ngroup_tile + si, gi & 1);
+        if (!(p.exp & 4)) issue_group(spass * ngroup_tile + si, gi % NBUF);
         ++gi;
         if (++si == ngroup_tile) {
             si = 0;
@@ -389,17 +402,21 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             if (++spass == p.npass) spass = 0;
         }
     };
+    const uint32_t a_lane = lds_addr(WB) + mh * TH * 1024 + lane * 16;   // this wave's weight fragments inside a ring buffer
+    bf16x8 af0[TH], af1[TH];
     if (tile < ntiles) {
-        issue_next_group(p.npass > 1 || tile + (int)gridDim.x < ntiles);
+        const bool after = p.npass > 1 || tile + (int)gridDim.x < ntiles;
+        issue_next_group(after);
+        issue_next_group(after);
         for (int ph = 0; ph < NREG; ++ph) {
-            const XTarget t = x_target(tile, ph);
+            const XTarget t = x_target(tile, ph, ph);
             for (int xg = 0; xg < XG; ++xg) issue_x(t, xg);
         }
-        wait_vm0();      // the first tile's X regions (the weight group with them): simplest to drain here
+        wait_vm0();      // the first item's X regions and weight groups: simplest to drain here
         landed = gi;
+        block_sync();
+        FragLoop<TH, 0, 0>::issue(a_lane, af0);      // step 0 of group 0
     }
-
-    const uint32_t a_lane = lds_addr(WB) + mh * TH * 1024 + lane * 16;   // this wave's weight fragments inside a ring buffer
 
 #ifdef MK_PCE_STAMPS   // profiling build only (tools/pce_stamps.py): the stamps cost registers in the hot loop
     int stamp_n = 0;
@@ -418,11 +435,12 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         // the item after this one: the next pass over the same tile, or the first pass over the next tile
         const bool last_pass = pass + 1 == p.npass;
         const int next_tile = last_pass ? tile + (int)gridDim.x : tile;
+        const bool item_after = next_tile < ntiles;
         const int b = tile / tiles_per_b;
         const long long n0 = (long long)(tile - b * tiles_per_b) * PN;
         f32x16 acc[TH];
         stamp();   // 0: tile start
-        if (si_next) si_next = false;               // the stream's "next tile" is this tile now
+        if (si_next) si_next = false;               // the stream's "next item" is this item now
 #pragma unroll
         for (int i = 0; i < TH; ++i)
 #pragma unroll
@@ -430,6 +448,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         auto run_phase = [&](const int phase) {
             // ---- X phase: every wave has retired its pieces of this region (see the schedule above); the barrier makes
             //      them visible; pull this wave's pixel columns into registers ----
+            const int region = q & (NREG - 1);
             block_sync();
             stamp();   // 1
             bf16x8 xf[KSP];
@@ -437,63 +456,70 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                 const int l = opaque_lane();
                 const int rowq = (l & 15) >> 2;
                 const int ch = 4 * pg + 2 * ((l >> 4) & 1) + ((l & 3) >> 1);
-                const char* xfrag_lane = XS + (phase & (NREG - 1)) * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
+                const char* xfrag_lane = XS + region * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
                                          ((ch + 4 * rowq) & 15) * 16 + (l & 1) * 8;
                 if (!(p.exp & 16))
 #pragma unroll
                 for (int s = 0; s < KSP; ++s) {
-                    const char* q = xfrag_lane + s * 16 * XROW;
+                    const char* qp = xfrag_lane + s * 16 * XROW;
                     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(q));
+                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(qp));
                     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(q + 4 * XROW));
+                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(qp + 4 * XROW));
                     xf[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             block_sync();                                       // the region may be overwritten
             stamp();   // 2
-            // fetched into this region while the phase computes: the phase NREG ahead (of this tile, or of the next one)
+            // fetched into this region while the phase computes: the phase NREG ahead (of this item, or of the next one)
             XTarget xt;
             xt.active = false;
             if (!(p.exp & 8)) {
-                if (phase + NREG < NPH) xt = x_target(tile, phase + NREG);
-                else if (next_tile < ntiles) xt = x_target(next_tile, phase + NREG - NPH);
+                if (phase + NREG < NPH) xt = x_target(tile, phase + NREG, region);
+                else if (item_after) xt = x_target(next_tile, phase + NREG - NPH, region);
             }
+            ++q;
 #pragma unroll
             for (int gq = 0; gq < NG; ++gq) {
-                stamp();   // 3 + 3 gq
-                if (g >= landed) {                              // my pieces of group g: all but my cx youngest operations
+                const bool more1 = phase * NG + gq + 1 < ngroup_tile || item_after;   // group g + 1 exists
+                stamp();   // 3 + 2 gq
+                if (more1 && g + 1 >= landed) {                 // my pieces of group g + 1: all but my cx youngest operations
                     if (cx >= 2) wait_vm<2>();
                     else if (cx == 1) wait_vm<1>();
                     else wait_vm0();
                 }
-                stamp();   // 4 + 3 gq
-                if (!(p.exp & 32)) block_sync();                // group g complete; everyone is done with group g - 1
-                stamp();   // 5 + 3 gq
-                issue_next_group(next_tile < ntiles);
+                if (!(p.exp & 32)) block_sync();                // group g + 1 visible; nobody reads group g - 1 any more
+                stamp();   // 4 + 2 gq
+                issue_next_group(item_after);                   // group g + 2 -> the buffer of group g - 1
                 cx = (gq < XG && xt.active) ? issue_x(xt, gq) : 0;
                 if (!(p.exp & 2)) {
-                    const uint32_t a = a_lane + (g & 1) * GROUP;
-                    bf16x8 af[TH];
+                    const uint32_t a = a_lane + (g % NBUF) * GROUP;
+                    FragLoop<TH, 0, 0>::issue(a + SLOT, af1);                       // step 1 of group g
+                    wait_lgkm<TH>();                                                // af0 (older) has arrived
 #pragma unroll
-                    for (int s = 0; s < GS; ++s) {
-                        FragLoop<TH, 0, 0>::issue(a + s * SLOT, af);
-                        FragLoop<TH, 0, 0>::template mfma<TH>(af, xf[GS * gq + s], acc);
-                    }
+                    for (int t = 0; t < TH; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[GS * gq], af0[t], acc[t], 0, 0, 0);   // D[pixel][m]
+                    wait_lgkm<0>();                                                 // af1 has arrived
+                    if (more1) FragLoop<TH, 0, 0>::issue(a_lane + ((g + 1) % NBUF) * GROUP, af0);   // step 0 of group g + 1
+#pragma unroll
+                    for (int t = 0; t < TH; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[GS * gq + 1], af1[t], acc[t], 0, 0, 0);
                 }
                 ++g;
             }
         };
         run_phase(0);
         if constexpr (NPH >= 2) run_phase(1);
-        if constexpr (NPH >= 4) {
-            run_phase(2);
+        if constexpr (NPH >= 3) run_phase(2);
+        if constexpr (NPH >= 6) {
             run_phase(3);
+            run_phase(4);
+            run_phase(5);
         }
         stamp();   // epilogue start
-        // everything this wave has in flight (the next weight group, late X pieces) lands before the epilogue's stores are
-        // queued behind it: no later wait has to sit out a store's round trip
+        // everything this wave has in flight (weight groups of the next item, late X pieces) lands before the epilogue's
+        // stores are queued behind it: no later wait has to sit out a store's round trip
         wait_vm0();
         landed = gi;
         cx = 0;
@@ -501,7 +527,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         if (!(p.exp & 1)) {
             EpiAddr ea;
             const int l = opaque_lane();
-            const uint32_t stg = lds_addr(WB) + 2 * GROUP + wave * 2048;    // wave-private [32 rows][32 px] bf16 tile
+            const uint32_t stg = lds_addr(WB) + NBUF * GROUP + wave * 2048;    // wave-private [32 rows][32 px] bf16 tile
             const int ml = l & 31;
             ea.rot = (ml >> 1) & 3;
             ea.st_acc = stg + ml * 64 + (l >> 5) * 8;
@@ -509,7 +535,8 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             ea.px_lin = (l & 3) * 8;
             ea.st_lin = stg + ea.row_lin * 64 + (((l & 3) + (ea.row_lin >> 1)) & 3) * 16;
             const long long px0 = n0 + 32 * pg;
-            pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.M * p.P + px0, px0 + ea.px_lin < p.P);
+            pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.M * p.P + px0,
+                                     px0 + ea.px_lin < p.P);
         } else {
 #pragma unroll
             for (int t = 0; t < TH; ++t) keep_alive(acc[t]);
@@ -573,8 +600,9 @@ struct PceCfg {
 };
 static bool pce_config(int M, int K, PceCfg* c) {
     if (M <= 0 || K <= 0 || K > 768) return false;
-    c->KSP = K > 96 ? 12 : (K > 32 ? 6 : 2);            // k16 steps per phase
-    c->NPH = K > 384 ? 4 : (K > 192 ? 2 : 1);           // phases of 16 KSP rows (K in (384, 576] pads to four)
+    c->KSP = K > 64 ? 8 : (K > 32 ? 4 : 2);             // k16 steps per phase: phases of <= 128 k rows
+    const int nph = mk::ceil_div(K, 128);
+    c->NPH = nph > 3 ? 6 : nph;                         // built for 1, 2, 3 and 6 phases (4 and 5 pad to six)
     c->TH = M > 128 ? 6 : (M > 64 ? 2 : 1);
     c->npass = mk::ceil_div(M, 64 * c->TH);
     return true;
@@ -583,7 +611,7 @@ static long long pce_image_core_bytes(const PceCfg& c) { return (long long)c.npa
 
 template <int KSP, int NPH, int TH, bool HAS_IN>
 static int pce_launch(const PceParams& p, hipStream_t st) {
-    constexpr int LDS = (NPH > 1 ? 2 : 1) * 16 * KSP * XROW + 2 * 2 * 2 * TH * 1024 + 8 * 2048;   // X regions + two weight groups + 8 staging tiles
+    constexpr int LDS = (NPH > 1 ? 2 : 1) * 16 * KSP * XROW + 3 * 2 * 2 * TH * 1024 + 8 * 2048;   // X regions + three weight groups + 8 staging tiles
     static const bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pce_kernel<KSP, NPH, TH, HAS_IN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -673,10 +701,11 @@ extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float
             done = true;                                                                                        \
         }
         MK_PCE_CASE(2, 1, 1) MK_PCE_CASE(2, 1, 2) MK_PCE_CASE(2, 1, 6)
-        MK_PCE_CASE(6, 1, 1) MK_PCE_CASE(6, 1, 2) MK_PCE_CASE(6, 1, 6)
-        MK_PCE_CASE(12, 1, 1) MK_PCE_CASE(12, 1, 2) MK_PCE_CASE(12, 1, 6)
-        MK_PCE_CASE(12, 2, 1) MK_PCE_CASE(12, 2, 2) MK_PCE_CASE(12, 2, 6)
-        MK_PCE_CASE(12, 4, 1) MK_PCE_CASE(12, 4, 2) MK_PCE_CASE(12, 4, 6)
+        MK_PCE_CASE(4, 1, 1) MK_PCE_CASE(4, 1, 2) MK_PCE_CASE(4, 1, 6)
+        MK_PCE_CASE(8, 1, 1) MK_PCE_CASE(8, 1, 2) MK_PCE_CASE(8, 1, 6)
+        MK_PCE_CASE(8, 2, 1) MK_PCE_CASE(8, 2, 2) MK_PCE_CASE(8, 2, 6)
+        MK_PCE_CASE(8, 3, 1) MK_PCE_CASE(8, 3, 2) MK_PCE_CASE(8, 3, 6)
+        MK_PCE_CASE(8, 6, 1) MK_PCE_CASE(8, 6, 2) MK_PCE_CASE(8, 6, 6)
 #undef MK_PCE_CASE
         MK_REQUIRE(done, "no kernel instance for this shape");
         MK_LAUNCH_CHECK();

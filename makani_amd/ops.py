@@ -388,6 +388,16 @@ def pce_pack(w, transpose=False):
     return img
 
 
+_ZERO_BIAS = {}
+
+
+def _zero_bias(device):
+    z = _ZERO_BIAS.get(device)
+    if z is None:
+        z = _ZERO_BIAS[device] = torch.zeros(1024, dtype=torch.float32, device=device)
+    return z
+
+
 def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False):
     """y[b] = epi(A @ x3[b]) on bf16 ``[B, K, P]`` fields (see ``mk_pce_gemm``).  Returns ``y`` or ``(y, pre)`` with
     ``pre`` the bf16 pre-activation ``A x + bias`` when ``want_pre``."""
@@ -397,13 +407,13 @@ def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, g
     for t in (addend, aux_in):
         if t is not None:
             assert t.is_contiguous() and t.dtype == torch.bfloat16 and tuple(t.shape) == (b, m, p)
-    bf = None
-    if bias is not None:      # fp32, padded to whole passes of the kernel (its epilogue loads the bias unconditionally)
+    bf = _zero_bias(x3.device)   # the epilogue loads a bias unconditionally: zeros for layers without one
+    if bias is not None:      # fp32, padded to whole passes of the kernel
         bf = torch.zeros((m + 383) // 384 * 384, dtype=torch.float32, device=x3.device)
         bf[:m] = bias.detach()
     y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
     pre = torch.empty_like(y) if want_pre else None
-    _lib.check(_lib.load().mk_pce_gemm(x3.data_ptr(), wimg.data_ptr(), y.data_ptr(), None if bf is None else bf.data_ptr(),
+    _lib.check(_lib.load().mk_pce_gemm(x3.data_ptr(), wimg.data_ptr(), y.data_ptr(), bf.data_ptr(),
                                        None if addend is None else addend.data_ptr(),
                                        None if aux_in is None else aux_in.data_ptr(),
                                        None if pre is None else pre.data_ptr(), int(bool(gelu)), b, m, k, p, _stream()),

@@ -15,7 +15,7 @@ import os
 import sys
 from collections import defaultdict
 
-NAMES = [("irfft", "irfft_split_kernel"), ("irfft", "irfft_kernel"), ("rfft", "rfft_split_kernel"), ("rfft", "rfft_kernel"),
+NAMES = [("pce_gemm", "pce_kernel"), ("adam", "adam_kernel"), ("irfft", "irfft_split_kernel"), ("irfft", "irfft_kernel"), ("rfft", "rfft_split_kernel"), ("rfft", "rfft_kernel"),
          ("legendre_fwd", "legendre_fwd_x3_kernel"), ("legendre_inv", "legendre_inv_x3_kernel"),
          ("dhconv_fwd", "dhconv_fwd_x3_kernel"), ("dhconv_dgrad", "dhconv_dgrad_x3_kernel"),
          ("dhconv_wgrad", "dhconv_wgrad_x3_kernel"),
