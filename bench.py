@@ -100,7 +100,7 @@ class KernelTimer:
             i = x3.shape[1]
             return float(2 * (o + i) * p * b + 4 * o * i), "byte"
 
-        def pce_work(out, x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False):
+        def pce_work(out, x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False, want_row_sums=False):
             # every 1x1 convolution of the net sits below the bf16 ridge (intensity M*K/(M+K) <= 256 flop per byte):
             # HBM is the roof -- X read once, Y written once, plus the optional second input / second output
             b, k, p = x3.shape

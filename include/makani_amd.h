@@ -249,6 +249,12 @@ int mk_pce_pack(const void* w, int w_dtype /* 0 fp32, 1 bf16 */, int transpose, 
                 void* stream);
 int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const void* aux_in,
                 void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream);
+/* The same with the per-row sums of the stored output as a by-product: rowstats [B][M][2] (double) receives sum and sum of
+ * squares over the pixels of every y row -- the statistics pass of the instance norm that follows an MLP (sfnonet.py:262-263)
+ * and the bias gradient of a convolution (sum over pixels of the output gradient) without another pass over the field.
+ * M <= 768; the buffer is zeroed by the call. */
+int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const void* aux_in,
+                   void* aux_out, int gelu, double* rowstats, int batch, int M, int K, long long P, void* stream);
 /* Profiling aid (tools/pce_stamps.py): with MK_PCE_DBG=1 in the environment the kernel records s_memtime stamps of
  * workgroup 0; this copies the 8 x 64 stamps of the last launch to the host. */
 int mk_pce_debug_stamps(unsigned long long* out512);

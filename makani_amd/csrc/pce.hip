@@ -51,6 +51,7 @@ struct PceParams {
     const __hip_bfloat16* addend;  // [B][M][P] or null: y += addend
     const __hip_bfloat16* aux_in;  // [B][M][P] or null: y *= gelu'(aux_in)   (applied before the addend)
     __hip_bfloat16* aux_out;       // [B][M][P] or null: pre-activation (acc + bias) stored here
+    double* rowstats;              // [B][M][2] or null: += (sum, sum of squares) over the pixels of the stored y rows
     int gelu;                      // y = gelu(acc + bias)
     int M, K, B;                   // M: output rows of the whole field
     int npass;                     // passes of 64 TH rows over the same X tile (the second pass finds it in L2)
@@ -132,6 +133,14 @@ __device__ __forceinline__ u32x2 lds_read_tr16(uint32_t addr) {
     asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
     return v;
 }
+__device__ __forceinline__ void lds_write_b32(uint32_t addr, float v) {
+    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+__device__ __forceinline__ float lds_read_b32(uint32_t addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
+    return v;
+}
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     const bf16x2 t = {(__bf16)lo, (__bf16)hi};
@@ -203,7 +212,8 @@ __device__ __forceinline__ u32x2 lds_read_b64(uint32_t addr) {
 // per weight group, the whole HBM latency of the X pieces in flight).
 template <int TH, bool HAS_IN>
 __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[TH], const EpiAddr& ea, int m_first, int m_local,
-                                             long long tile_base /* b*M*P + n0 + 32 pg */, bool px_ok) {
+                                             long long tile_base /* b*M*P + n0 + 32 pg */, bool px_ok, int gmask,
+                                             float (&ts1)[TH], float (&ts2)[TH]) {
     const unsigned short* in = reinterpret_cast<const unsigned short*>(p.aux_in ? p.aux_in : p.addend);
     constexpr bool has_in = HAS_IN;
     const bool mul_gelu_grad = p.aux_in != nullptr;
@@ -282,6 +292,24 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
         }
         stage(v);
         flush(reinterpret_cast<unsigned short*>(p.y), t);
+        if (p.rowstats) {
+            // row sums of what was stored (the bf16-rounded values), valid 8-pixel groups only; this lane's row is m_local
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (gmask & (1 << g)) {
+#pragma unroll
+                    for (int j = 0; j < 4; j += 2) {
+                        const uint32_t pk = pack_bf16x2(v[4 * g + j], v[4 * g + j + 1]);
+                        const float a = __uint_as_float(pk << 16), b = __uint_as_float(pk & 0xFFFF0000u);
+                        s1 += a + b;
+                        s2 = fmaf(a, a, fmaf(b, b, s2));
+                    }
+                }
+            }
+            ts1[t] += s1;
+            ts2[t] += s2;
+        }
     }
 }
 
@@ -430,6 +458,54 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
 #else
     auto stamp = [&]() {};
 #endif
+    // per-row sums of the output (p.rowstats): accumulated per lane over the tiles of one batch item, one set per pass
+    float rs1[2][TH], rs2[2][TH];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int t = 0; t < TH; ++t) rs1[i][t] = rs2[i][t] = 0.f;
+    int rs_b = -1;
+    auto flush_rowstats = [&]() {       // every wave of the workgroup calls this at the same points
+        if (!p.rowstats || rs_b < 0) return;
+        const uint32_t stg = lds_addr(WB) + NBUF * GROUP;         // the 8 staging tiles (2 KB each): [wave][(t, k)][32 rows] floats
+        const int l = opaque_lane();
+        const int ml = l & 31;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                             // one pass' set at a time: TH * 2 * 128 B <= 2 KB per wave
+            if (i < p.npass) {
+#pragma unroll
+                for (int t = 0; t < TH; ++t) {
+                    const float a = rs1[i][t] + __shfl_xor(rs1[i][t], 32), b = rs2[i][t] + __shfl_xor(rs2[i][t], 32);
+                    if (l < 32) {
+                        lds_write_b32(stg + wave * 2048 + (t * 2 + 0) * 128 + ml * 4, a);
+                        lds_write_b32(stg + wave * 2048 + (t * 2 + 1) * 128 + ml * 4, b);
+                    }
+                }
+                wait_lgkm<0>();
+                block_sync();
+                if (pg == 0 && l < 32) {
+                    for (int t = 0; t < TH; ++t) {
+                        const int m = i * 64 * TH + mh * 32 * TH + 32 * t + ml;
+                        float a = 0.f, b = 0.f;
+                        for (int w = 0; w < 4; ++w) {
+                            const float a1 = lds_read_b32(stg + (mh * 4 + w) * 2048 + (t * 2 + 0) * 128 + ml * 4);
+                            const float b1 = lds_read_b32(stg + (mh * 4 + w) * 2048 + (t * 2 + 1) * 128 + ml * 4);
+                            wait_lgkm<0>();
+                            a += a1;
+                            b += b1;
+                        }
+                        if (m < p.M) {
+                            atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2, (double)a);
+                            atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2 + 1, (double)b);
+                        }
+                    }
+                }
+                block_sync();
+            }
+#pragma unroll
+            for (int t = 0; t < TH; ++t) rs1[i][t] = rs2[i][t] = 0.f;
+        }
+    };
     for (; tile < ntiles; tile += gridDim.x)
     for (int pass = 0; pass < p.npass; ++pass) {
         // the item after this one: the next pass over the same tile, or the first pass over the next tile
@@ -535,14 +611,34 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             ea.px_lin = (l & 3) * 8;
             ea.st_lin = stg + ea.row_lin * 64 + (((l & 3) + (ea.row_lin >> 1)) & 3) * 16;
             const long long px0 = n0 + 32 * pg;
+            if (p.rowstats && b != rs_b) {          // a new batch item: hand over the sums of the previous one
+                flush_rowstats();
+                rs_b = b;
+            }
+            int gmask = 0;
+#pragma unroll
+            for (int gg = 0; gg < 4; ++gg) gmask |= (px0 + 8 * gg < p.P) ? (1 << gg) : 0;
+            float ts1[TH], ts2[TH];
+#pragma unroll
+            for (int t = 0; t < TH; ++t) ts1[t] = ts2[t] = 0.f;
             pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.M * p.P + px0,
-                                     px0 + ea.px_lin < p.P);
+                                     px0 + ea.px_lin < p.P, gmask, ts1, ts2);
+            if (p.rowstats) {
+                if (pass == 0) {
+#pragma unroll
+                    for (int t = 0; t < TH; ++t) { rs1[0][t] += ts1[t]; rs2[0][t] += ts2[t]; }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < TH; ++t) { rs1[1][t] += ts1[t]; rs2[1][t] += ts2[t]; }
+                }
+            }
         } else {
 #pragma unroll
             for (int t = 0; t < TH; ++t) keep_alive(acc[t]);
         }
         stamp();   // epilogue end
     }
+    flush_rowstats();
     // drain: nothing may be in flight into LDS when the workgroup's LDS is released
     wait_vm0();
 }
@@ -655,8 +751,21 @@ extern "C" int mk_pce_pack(const void* w, int w_dtype, int transpose, int M, int
     return 0;
 }
 
+namespace {
+__global__ void pce_zero_kernel(double* p, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+}  // namespace
+
 extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend,
                            const void* aux_in, void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream) {
+    return mk_pce_gemm_ex(x, wimg, y, bias, addend, aux_in, aux_out, gelu, nullptr, batch, M, K, P, stream);
+}
+
+extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const float* bias, const void* addend,
+                              const void* aux_in, void* aux_out, int gelu, double* rowstats, int batch, int M, int K,
+                              long long P, void* stream) {
     MK_REQUIRE(x && wimg && y, "null pointer");
     MK_REQUIRE(batch > 0 && M > 0 && K > 0 && P > 0, "bad sizes");
     MK_REQUIRE((P % 8) == 0, "P = H*W must be a multiple of 8 (16-byte row alignment)");
@@ -666,6 +775,11 @@ extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float
     static const int pexp = [] { const char* e = getenv("MK_PCE_EXP"); return e ? atoi(e) : 0; }();
     MK_REQUIRE(!(addend && aux_in), "addend and aux_in are exclusive");
     hipStream_t st = (hipStream_t)stream;
+    if (rowstats) {
+        MK_REQUIRE(c.npass <= 2, "row statistics are built for M <= 768");
+        const long long n = 2LL * batch * M;
+        hipLaunchKernelGGL(pce_zero_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, rowstats, n);
+    }
     const float* zero_bias = bias ? nullptr : pce_zero_bias();
     MK_REQUIRE(bias || zero_bias, "cannot allocate the zero bias");
     const long long tiles_per_b = (P + PN - 1) / PN;
@@ -682,6 +796,7 @@ extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float
         p.addend = (const __hip_bfloat16*)addend;
         p.aux_in = (const __hip_bfloat16*)aux_in;
         p.aux_out = (__hip_bfloat16*)aux_out;
+        p.rowstats = rowstats;
         p.gelu = gelu;
         p.M = M;
         p.K = K;

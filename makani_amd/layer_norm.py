@@ -59,13 +59,13 @@ class DistributedInstanceNorm2d(nn.Module):
             self._counts[key] = int(round(t.item()))
         return self._counts[key]
 
-    def forward(self, x, fuse_gelu=False):
+    def forward(self, x, fuse_gelu=False, row_sums=None):
         from . import ops
         if x.is_cuda and x.dim() == 4 and ops.pointwise_supported(x) and comm.get_size("spatial") > 1:
             # HIP path: local row sums -> one all-reduce of [B*C, 2] doubles -> apply (+ fused GELU); same two
             # streaming passes as the single-GPU norm instead of ~10 elementwise torch passes in fp32
             return ops.instance_norm(x.contiguous(), self.weight if self.affine else None, self.bias if self.affine else None,
-                                     self.eps, fuse_gelu, comm.get_group("spatial"), self._global_count(x))
+                                     self.eps, fuse_gelu, comm.get_group("spatial"), self._global_count(x), row_sums)
         y = self._forward_torch(x)
         return torch.nn.functional.gelu(y) if fuse_gelu else y
 

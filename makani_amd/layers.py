@@ -127,33 +127,41 @@ class _PceMLP(torch.autograd.Function):
     wrappers that expect every parameter to get a gradient (DistributedDataParallel, ``mpu/mappings.py:86-96``) work."""
 
     @staticmethod
-    def forward(ctx, x3, w1, b1, w2, b2, apply_b2):
+    def forward(ctx, x3, w1, b1, w2, b2, apply_b2, want_row_sums):
         from . import ops
         h, pre = ops.pce_gemm(x3, ops.pce_pack(w1), w1.shape[0], bias=b1, want_pre=True, gelu=True)
-        y = ops.pce_gemm(h, ops.pce_pack(w2), w2.shape[0], bias=b2 if (apply_b2 and b2 is not None) else None)
+        want_row_sums = bool(want_row_sums) and w2.shape[0] <= 768
+        y = ops.pce_gemm(h, ops.pce_pack(w2), w2.shape[0], bias=b2 if (apply_b2 and b2 is not None) else None,
+                         want_row_sums=want_row_sums)
+        y, sums = y if want_row_sums else (y, x3.new_empty(0, dtype=torch.float64))
         ctx.save_for_backward(x3, w1, w2, pre, h)
         ctx.cfg = (None if b1 is None else b1.dtype, None if b2 is None else (b2.dtype, tuple(b2.shape)), bool(apply_b2))
-        return y
+        ctx.mark_non_differentiable(sums)
+        return y, sums
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, _gsums):
         from . import ops
         x3, w1, w2, pre, h = ctx.saved_tensors
         b1_dtype, b2_info, apply_b2 = ctx.cfg
         gy = gy.contiguous()
-        gpre = ops.pce_gemm(gy, ops.pce_pack(w2, transpose=True), w2.shape[1], aux_in=pre)
+        need_gb1 = b1_dtype is not None and ctx.needs_input_grad[2]
+        fused_gb1 = need_gb1 and w2.shape[1] <= 768
+        gpre = ops.pce_gemm(gy, ops.pce_pack(w2, transpose=True), w2.shape[1], aux_in=pre, want_row_sums=fused_gb1)
+        if fused_gb1:       # the bias gradient is the pixel sum of gpre: a by-product of the launch that wrote it
+            gpre, gsum = gpre
         gx = gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[0]:
             gx = ops.pce_gemm(gpre, ops.pce_pack(w1, transpose=True), w1.shape[1])
         if ctx.needs_input_grad[1]:
             gw1 = ops.conv1x1_wgrad_raw(gpre, x3).to(w1.dtype)
-        if b1_dtype is not None and ctx.needs_input_grad[2]:
-            gb1 = _row_sums(gpre).to(b1_dtype)
+        if need_gb1:
+            gb1 = (gsum.view(gy.shape[0], -1, 2)[..., 0].sum(0) if fused_gb1 else _row_sums(gpre)).to(b1_dtype)
         if ctx.needs_input_grad[3]:
             gw2 = ops.conv1x1_wgrad_raw(gy, h).to(w2.dtype)
         if b2_info is not None and ctx.needs_input_grad[4]:
             gb2 = _row_sums(gy).to(b2_info[0]) if apply_b2 else torch.zeros(b2_info[1], dtype=b2_info[0], device=gy.device)
-        return gx, gw1, gb1, gw2, gb2, None
+        return gx, gw1, gb1, gw2, gb2, None, None
 
 
 def _engine_field(x):
@@ -227,7 +235,7 @@ def _mlp_pattern(mods):
     return convs[0], convs[1]
 
 
-def run_pointwise_chain(mods, x, skip_last_bias=False):
+def run_pointwise_chain(mods, x, skip_last_bias=False, want_row_sums=False):
     """Evaluate an ``nn.Sequential`` of 1x1 convs / activations / identities.
 
     The two-convolution pattern of ``MLP`` and ``EncoderDecoder`` (conv + bias, exact GELU, conv) runs as one fused
@@ -237,6 +245,9 @@ def run_pointwise_chain(mods, x, skip_last_bias=False):
     ``skip_last_bias``: the caller feeds the result straight into an instance norm without running statistics, which
     removes any per-channel constant -- the last conv's bias add is then a no-op on the output and its gradient is
     exactly zero, so the add is skipped (the parameter still receives that zero gradient).
+
+    ``want_row_sums``: return ``(y, sums)`` with ``sums`` the fp64 ``[B * C, 2]`` per-row (sum, sum of squares) of ``y``
+    when the engine produced them alongside (else ``None``) -- the statistics of the instance norm that follows.
     """
     from . import ops
     mods = list(mods)
@@ -247,8 +258,10 @@ def run_pointwise_chain(mods, x, skip_last_bias=False):
         if (x3 is not None and ops.pce_supported(fc1.out_channels, fc1.in_channels)
                 and ops.pce_supported(fc2.out_channels, fc2.in_channels)):
             with torch.autocast("cuda", enabled=False):
-                y = _PceMLP.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias)
-            return y.view(x.shape[0], fc2.out_channels, x.shape[2], x.shape[3])
+                y, sums = _PceMLP.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias,
+                                        want_row_sums)
+            y = y.view(x.shape[0], fc2.out_channels, x.shape[2], x.shape[3])
+            return (y, sums if sums.numel() else None) if want_row_sums else y
     last_conv = max((j for j, m in enumerate(mods) if isinstance(m, Conv1x1)), default=-1)
     tail_is_noop = all(_is_noop(m) for m in mods[last_conv + 1:])
     i = 0
@@ -270,7 +283,7 @@ def run_pointwise_chain(mods, x, skip_last_bias=False):
         else:
             x = m(x)
             i += 1
-    return x
+    return (x, None) if want_row_sums else x
 
 
 class _ZeroGradBias(torch.autograd.Function):
@@ -290,12 +303,12 @@ class InstanceNorm2d(nn.InstanceNorm2d):
     """``nn.InstanceNorm2d(affine=True, track_running_stats=False)`` as two HIP streaming passes
     (row sums, apply), optionally with the block's GELU fused into the apply pass."""
 
-    def forward(self, x, fuse_gelu=False):
+    def forward(self, x, fuse_gelu=False, row_sums=None):
         from . import ops
         if self.track_running_stats or not ops.pointwise_supported(x):
             y = super().forward(x)
             return F.gelu(y) if fuse_gelu else y
-        return ops.instance_norm(x, self.weight, self.bias, self.eps, fuse_gelu)
+        return ops.instance_norm(x, self.weight, self.bias, self.eps, fuse_gelu, row_sums=row_sums)
 
 
 def drop_path(x, drop_prob=0.0, training=False):
@@ -393,16 +406,18 @@ class MLP(nn.Module):
             drop = nn.Identity()
         self.fwd = nn.Sequential(fc1, act, drop, fc2, drop)
 
-    def _run(self, x, skip_last_bias=False):
-        return run_pointwise_chain(self.fwd, x, skip_last_bias)
+    def _run(self, x, skip_last_bias=False, want_row_sums=False):
+        return run_pointwise_chain(self.fwd, x, skip_last_bias, want_row_sums)
 
     def checkpoint_forward(self, x, skip_last_bias=False):
         return checkpoint(self._run, x, skip_last_bias, use_reentrant=False)
 
-    def forward(self, x, skip_last_bias=False):
+    def forward(self, x, skip_last_bias=False, want_row_sums=False):
+        """``want_row_sums``: return ``(y, sums)`` -- see ``run_pointwise_chain``."""
         if self.checkpointing >= 2:
-            return self.checkpoint_forward(x, skip_last_bias)
-        return self._run(x, skip_last_bias)
+            y = self.checkpoint_forward(x, skip_last_bias)
+            return (y, None) if want_row_sums else y
+        return self._run(x, skip_last_bias, want_row_sums)
 
 
 class RealFFT2(nn.Module):

@@ -398,9 +398,10 @@ def _zero_bias(device):
     return z
 
 
-def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False):
-    """y[b] = epi(A @ x3[b]) on bf16 ``[B, K, P]`` fields (see ``mk_pce_gemm``).  Returns ``y`` or ``(y, pre)`` with
-    ``pre`` the bf16 pre-activation ``A x + bias`` when ``want_pre``."""
+def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False, want_row_sums=False):
+    """y[b] = epi(A @ x3[b]) on bf16 ``[B, K, P]`` fields (see ``mk_pce_gemm_ex``).  Returns ``y``, followed by ``pre``
+    (the bf16 pre-activation ``A x + bias``) when ``want_pre`` and by the fp64 ``[B * M, 2]`` row sums (sum, sum of squares
+    over the pixels of ``y``) when ``want_row_sums``."""
     _need_cuda(x3, wimg)
     assert x3.dim() == 3 and x3.is_contiguous() and x3.dtype == torch.bfloat16
     b, k, p = x3.shape
@@ -413,12 +414,15 @@ def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, g
         bf[:m] = bias.detach()
     y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
     pre = torch.empty_like(y) if want_pre else None
-    _lib.check(_lib.load().mk_pce_gemm(x3.data_ptr(), wimg.data_ptr(), y.data_ptr(), bf.data_ptr(),
-                                       None if addend is None else addend.data_ptr(),
-                                       None if aux_in is None else aux_in.data_ptr(),
-                                       None if pre is None else pre.data_ptr(), int(bool(gelu)), b, m, k, p, _stream()),
-               "mk_pce_gemm")
-    return (y, pre) if want_pre else y
+    sums = torch.empty(b * m, 2, dtype=torch.float64, device=x3.device) if want_row_sums else None
+    _lib.check(_lib.load().mk_pce_gemm_ex(x3.data_ptr(), wimg.data_ptr(), y.data_ptr(), bf.data_ptr(),
+                                          None if addend is None else addend.data_ptr(),
+                                          None if aux_in is None else aux_in.data_ptr(),
+                                          None if pre is None else pre.data_ptr(), int(bool(gelu)),
+                                          None if sums is None else sums.data_ptr(), b, m, k, p, _stream()),
+               "mk_pce_gemm_ex")
+    out = (y,) + ((pre,) if want_pre else ()) + ((sums,) if want_row_sums else ())
+    return out if len(out) > 1 else y
 
 
 # ----------------------------------------------------------------------------
@@ -660,14 +664,16 @@ class _InstanceNorm(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, fuse_gelu, group, count):
+    def forward(ctx, x, weight, bias, eps, fuse_gelu, group, count, sums=None):
         _need_cuda(x)
         B, C, H, W = x.shape
         y = torch.empty_like(x)
         wf = None if weight is None else weight.detach().float().contiguous()
         bf = None if bias is None else bias.detach().float().contiguous()
         stats = torch.empty(B * C, 2, dtype=torch.float32, device=x.device)
-        ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
+        if sums is not None:     # the producer of x delivered the local row sums (engine epilogue): statistics pass done
+            assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() == 2 * B * C
+        ws = sums if sums is not None else torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
         lib = _lib.load()
         cnt = H * W if group is None else int(count)
 
@@ -677,9 +683,10 @@ class _InstanceNorm(torch.autograd.Function):
                                               ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, cnt, float(eps),
                                               int(fuse_gelu), phase, _stream()), "mk_instnorm_fwd_ex")
         if group is None:
-            run(0)
+            run(0 if sums is None else 2)
         else:
-            run(1)
+            if sums is None:
+                run(1)
             torch.distributed.all_reduce(ws, group=group)
             run(2)
         empty = x.new_empty(0, dtype=torch.float32)
@@ -714,7 +721,7 @@ class _InstanceNorm(torch.autograd.Function):
         sums = local.view(B, C, 2).sum(0)
         gw = sums[:, 1].to(wdt) if has_w else None
         gb = sums[:, 0].to(bdt) if has_b else None
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 class _WeightedMSE(torch.autograd.Function):
@@ -769,5 +776,7 @@ def bias_gelu(x, bias):
     return _BiasGelu.apply(x, bias)
 
 
-def instance_norm(x, weight, bias, eps=1e-5, fuse_gelu=False, group=None, count=None):
-    return _InstanceNorm.apply(x, weight, bias, eps, fuse_gelu, group, count)
+def instance_norm(x, weight, bias, eps=1e-5, fuse_gelu=False, group=None, count=None, row_sums=None):
+    """``row_sums``: fp64 ``[B * C, 2]`` LOCAL (sum, sum of squares) of every row of ``x`` when its producer already has
+    them (``pce_gemm(..., want_row_sums=True)``); the statistics pass over ``x`` is then skipped."""
+    return _InstanceNorm.apply(x, weight, bias, eps, fuse_gelu, group, count, row_sums)

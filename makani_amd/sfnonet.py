@@ -126,9 +126,14 @@ class FourierNeuralOperatorBlock(nn.Module):
             if inner is not None:
                 x = x + inner(residual)
             x = self.act_layer0(x)
+        sums = None
         if hasattr(self, "mlp"):
-            x = self.mlp(x, skip_last_bias=self._removes_channel_constants(self.norm1))
-        x = self.drop_path(self.norm1(x))
+            if isinstance(self.norm1, (InstanceNorm2d, DistributedInstanceNorm2d)):
+                # the last GEMM of the MLP hands over the row sums of its output: norm1 needs no statistics pass
+                x, sums = self.mlp(x, skip_last_bias=self._removes_channel_constants(self.norm1), want_row_sums=True)
+            else:
+                x = self.mlp(x, skip_last_bias=self._removes_channel_constants(self.norm1))
+        x = self.drop_path(self.norm1(x, row_sums=sums) if sums is not None else self.norm1(x))
         outer = getattr(self, "outer_skip", None)
         if isinstance(outer, Conv1x1):
             x = outer(residual, addend=x)                     # skip add folded into the GEMM epilogue

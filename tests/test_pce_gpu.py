@@ -80,3 +80,37 @@ def test_pce_gelu_accuracy(dev):
     ones = torch.ones_like(xs)
     g = ops.pce_gemm(ones, img, M, aux_in=xs).double()
     assert _rel(g, _gelu_grad(xs.double())) < 3e-3
+
+
+@pytest.mark.parametrize("M,K,P,B", [(384, 768, 1000, 2), (768, 384, 520, 3), (73, 384, 264, 3), (16, 8, 2048, 2),
+                                     (384, 384, 128 * 300 + 40, 2)])
+def test_pce_row_sums(dev, M, K, P, B):
+    """The epilogue's by-product: per-row (sum, sum of squares) of the STORED output, with every epilogue variant; the
+    last shape gives each workgroup several tiles and a batch boundary inside its tile sequence."""
+    from makani_amd import ops
+    torch.manual_seed(5)
+    w = (torch.randn(M, K) / math.sqrt(K)).to(dev)
+    bias = torch.randn(M, device=dev)
+    x = torch.randn(B, K, P, device=dev).bfloat16()
+    aux = torch.randn(B, M, P, device=dev).bfloat16()
+    img = ops.pce_pack(w)
+    for kw in (dict(), dict(bias=bias, gelu=True), dict(aux_in=aux), dict(addend=aux)):
+        y, sums = ops.pce_gemm(x, img, M, want_row_sums=True, **kw)
+        assert torch.equal(y, ops.pce_gemm(x, img, M, **kw))
+        assert sums.shape == (B * M, 2) and sums.dtype == torch.float64
+        yd = y.double().view(B * M, P)
+        np.testing.assert_allclose(sums[:, 0].cpu().numpy(), yd.sum(1).cpu().numpy(), rtol=1e-4, atol=1e-3 * math.sqrt(P))
+        np.testing.assert_allclose(sums[:, 1].cpu().numpy(), (yd * yd).sum(1).cpu().numpy(), rtol=1e-4)
+
+
+def test_instance_norm_with_given_sums(dev):
+    from makani_amd import ops
+    torch.manual_seed(2)
+    B, C, H, W = 2, 24, 20, 40
+    w = torch.randn(C, 16, device=dev)
+    x = torch.randn(B, 16, H * W, device=dev).bfloat16()
+    y, sums = ops.pce_gemm(x, ops.pce_pack(w), C, want_row_sums=True)
+    g, b = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    a = ops.instance_norm(y.view(B, C, H, W), g, b, 1e-5)
+    c = ops.instance_norm(y.view(B, C, H, W), g, b, 1e-5, row_sums=sums)
+    assert _rel(c, a) < 1e-5
