@@ -226,6 +226,10 @@ int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const float* wrow
  * in MLP / EncoderDecoder / skip connections (layers.py:95-128,158-183; sfnonet.py:207,463). */
 int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
                      void* stream);
+/* The same contract, output-stationary: every workgroup keeps a 192 x 384 block of gw in registers for the whole launch and
+ * streams the operand rows through LDS once (csrc/wgrad_os.hip); gw is reached by one round of atomics at the end. */
+int mk_conv1x1_wgrad_os(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
+                        void* stream);
 
 /* Forward / data-gradient GEMM of the same convolution on bf16 NCHW fields:
  *   y[b][m][p] = sum_k a[m][k] * x[b][k][p] (+ addend[b][m][p], may be NULL),   fp32 accumulation, one rounding.

@@ -28,6 +28,8 @@
 #include <hip/hip_bf16.h>
 #include <cstdint>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -643,6 +645,376 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     wait_vm0();
 }
 
+// =====================================================================================================================
+// Weight-stationary variant: 64 < K <= 384, M > 128.
+//
+// What bounds the streaming kernel above is the weight stream itself: per 128-pixel tile a CU pulls 288 KB of weight
+// fragments out of L2 through the same in-order vector-memory path that carries the 96 KB X tile from HBM, with at most
+// ~80 KB in flight (the LDS ring) -- by Little's law that is 15 us per tile whatever the MFMAs do.  Here the weights never
+// move: a workgroup of 4 waves (one per SIMD, up to 512 registers each) loads the fragments of 384 output rows x K <= 384
+// ONCE (wave rg keeps rows 96 rg .. 96 rg + 95: 3 row tiles x 24 k16 steps x 4 VGPRs = 288 registers) and then only X
+// flows: 64-pixel tiles through a ring of ten 16 KB LDS regions (one region = one K phase of 128 rows x 64 px), filled
+// by LDS-DMA up to nine regions (144 KB) ahead.  Every wave reads the whole X tile out of LDS (transposing reads, 4 per
+// k16 step feeding 6 MFMAs) -- LDS traffic 43 B/clk of 256.  M = 768 runs as two row halves on different workgroups
+// of the same XCD (w and w + 8 walk the same tile sequence: the second fetch of an X tile finds it in that L2).
+//
+// Pixel order inside a 32-pixel MFMA tile: A-operand row 8 g + 4 h + i carries pixel 16 h + 4 g + i (the transposing
+// read takes any four 8-byte pieces per 16-lane group, so this costs nothing).  An accumulator then holds, for output row
+// m = lane % 32, the 16 CONSECUTIVE pixels 16 h .. 16 h + 15 (h = lane / 32) in its 16 registers: the epilogue packs them
+// and stores 2 x 16 bytes per lane straight to global memory -- no LDS transpose, no waits.
+//
+// The second input of the epilogue (addend / aux_in) comes through the same DMA ring as further regions per tile
+// ([rows][64 px], chunks rotated by row >> 1 so that the per-row ds_read_b128 of a tile spreads over the banks), so the
+// epilogue issues no vector loads at all and the only things in a wave's vmcnt queue are its DMA pieces (a static number
+// per slot) and its output stores.  vmcnt retires in issue order: "slot q has landed" is "all but my PW x (slots issued
+// after q) youngest operations"; stores queued since only make that wait stricter, never wrong.
+//
+// With one wave per SIMD nothing hides a wave's own overhead, so the DMA address arithmetic is incremental (a per-lane
+// pointer that steps by 8 rows) and its pieces are issued one by one in the shadow of the MFMAs of a k16 step.
+// =====================================================================================================================
+constexpr int WS_THREADS = 256;
+constexpr int WS_PN = 64;
+constexpr int WS_ROWS = 384;            // rows of one workgroup (4 waves x 3 row tiles)
+constexpr int WS_LDS = 160 * 1024;
+#ifdef MK_PCE_ABLATE     // profiling build only (tools/pce_ablate.py): the run-time checks cost the hot loop ~30 %
+#define WS_EXP(bit) (p.exp & (bit))
+#else
+#define WS_EXP(bit) false
+#endif
+
+template <int KSP, int NPH, bool HAS_IN>
+struct WsGeom {
+    static constexpr int RT = 3, NPT = 2;
+    static constexpr int KS = KSP * NPH;
+    static constexpr int PW = (2 * KSP + 3) / 4;              // 1 KB pieces (8 rows x 64 px) per wave and region
+    static constexpr int REG_BYTES = 4 * PW * 1024;
+    static constexpr int IN_ROWS = REG_BYTES / 128;           // rows of the second input per region
+    static constexpr int NIN = HAS_IN ? (WS_ROWS + IN_ROWS - 1) / IN_ROWS : 0;
+    static constexpr int NSLOT = NPH + NIN;                   // slots per tile: K phases of X, then the second input
+    static constexpr int R = WS_LDS / REG_BYTES > 12 ? 12 : WS_LDS / REG_BYTES;
+    static constexpr int cum(int ph) { return ph * NSLOT / NPH; }       // slots issued by the phases before ph
+    static constexpr int depth() {                            // slots in flight ahead of the one being consumed
+        int d = R;
+        for (int ph = 0; ph < NPH; ++ph) d = d < R + ph - cum(ph + 1) ? d : R + ph - cum(ph + 1);
+        return d;
+    }
+    static constexpr int D = depth();
+    static constexpr int LDS = R * REG_BYTES;
+    static_assert(D >= 2, "ring too small");
+    static_assert(PW * (D + NSLOT) < 64, "vmcnt is a 6-bit counter");
+};
+
+template <int KSP, int NPH, bool HAS_IN>
+__global__ __launch_bounds__(WS_THREADS, 1) void pce_ws_kernel(PceParams p) {
+    using G = WsGeom<KSP, NPH, HAS_IN>;
+    constexpr int RT = G::RT, NPT = G::NPT, KS = G::KS, PW = G::PW, REG_BYTES = G::REG_BYTES, IN_ROWS = G::IN_ROWS;
+    constexpr int NIN = G::NIN, R = G::R, D = G::D, NSLOT = G::NSLOT;
+    extern __shared__ __attribute__((aligned(1024))) char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // = row group
+    const int nh = p.npass;
+    const int half = ((int)blockIdx.x >> 3) % nh;
+    const int stream = ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * nh));
+    const int nstreams = (int)gridDim.x / nh;
+    const int tiles_per_b = (int)p.tiles_per_b;
+    const unsigned short* in2 = reinterpret_cast<const unsigned short*>(p.aux_in ? p.aux_in : p.addend);
+    const bool mul_gelu_grad = p.aux_in != nullptr;
+    const long long rowbytes = 2 * p.P;
+    auto opaque_lane = [&]() {
+        int l = lane;
+        asm volatile("" : "+v"(l));
+        return l;
+    };
+
+    // ---- the weights of this wave's 96 rows: resident for the whole launch ----
+    bf16x8 wf[KS][RT];
+    {
+        const char* wsrc = p.wimg + (long long)half * p.img_per_pass + (wave * RT) * 1024 + lane * 16;
+#pragma unroll
+        for (int s = 0; s < KS; ++s)
+#pragma unroll
+            for (int t = 0; t < RT; ++t) wf[s][t] = *reinterpret_cast<const bf16x8*>(wsrc + (s * 12 + t) * 1024);
+    }
+    const int m_first = half * WS_ROWS + wave * 32 * RT;
+    float bias_t[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) bias_t[t] = p.bias[m_first + 32 * t + (lane & 31)];
+
+    // ---- DMA issue side.  Slot sequence of a workgroup: (tile, slot 0 .. NSLOT-1), region = running slot index mod R.
+    //      One piece = 8 rows x 64 px; wave w issues pieces w PW .. w PW + PW - 1 of a region, so its rows are
+    //      8 (w PW + j) + (lane >> 3), walked by a per-lane pointer. ----
+    int it_b = 0, it_t = stream;            // tile of the slot being issued: batch item, tile inside it
+    while (it_t >= tiles_per_b && it_b < p.B) {
+        it_t -= tiles_per_b;
+        ++it_b;
+    }
+    int it_slot = 0, it_piece = 0, it_reg = 0;
+    const char* it_ptr = nullptr;           // this lane's source of the next piece (garbage when !it_ok)
+    int it_row = 0;                         // its row: k row (X slots) / row inside the 384-row half (second input)
+    bool it_ok = false;                     // tile inside the launch and this lane's pixels inside the field
+    auto start_slot = [&]() {               // called with it_piece == 0
+        const int l = opaque_lane();
+        const int r8 = l >> 3, cpos = l & 7;
+        const bool x_slot = !HAS_IN || it_slot < NPH;
+        // chunk rotation of the region images (source side: DMA writes lane-linear)
+        const int rot = x_slot ? 4 * ((r8 >> 1) & 1) : ((4 * wave * PW + (r8 >> 1)) & 7);
+        const int c = (cpos - rot) & 7;
+        const long long px = (long long)it_t * WS_PN + 8 * c;
+        it_ok = it_b < p.B && px < p.P;
+        if (x_slot) {
+            it_row = it_slot * 16 * KSP + 8 * wave * PW + r8;
+            it_ptr = reinterpret_cast<const char*>(p.x + ((long long)it_b * p.K + it_row) * p.P + px);
+        } else {
+            it_row = (it_slot - NPH) * IN_ROWS + 8 * wave * PW + r8;
+            it_ptr = reinterpret_cast<const char*>(in2 + ((long long)it_b * p.M + half * WS_ROWS + it_row) * p.P + px);
+        }
+    };
+    auto issue_piece = [&]() {
+        if (it_piece == 0) start_slot();
+        const bool x_slot = !HAS_IN || it_slot < NPH;
+        bool ok = it_ok;
+        const char* src = it_ptr;
+        if (x_slot) {
+            ok = ok && it_row < (it_slot + 1) * 16 * KSP && it_row < p.K;
+        } else {
+            ok = ok && it_row < WS_ROWS && half * WS_ROWS + it_row < p.M;
+            // the rotation of an input row depends on the piece: rows 8 n .. 8 n + 7 -> (4 n + (r8 >> 1)) & 7
+            if (it_piece & 1) {
+                const int l = opaque_lane();
+                const int cpos = l & 7, r8 = l >> 3;
+                const int c0 = (cpos - ((4 * wave * PW + (r8 >> 1)) & 7)) & 7, c1 = (c0 - 4) & 7;
+                src += 16 * (c1 - c0);
+                ok = it_b < p.B && (long long)it_t * WS_PN + 8 * c1 < p.P && it_row < WS_ROWS && half * WS_ROWS + it_row < p.M;
+            }
+        }
+        if (!WS_EXP(8)) dma16(ok ? (const void*)src : (const void*)p.zeros, lds + it_reg * REG_BYTES + (wave * PW + it_piece) * 1024);
+        it_ptr += 8 * rowbytes;
+        it_row += 8;
+        if (++it_piece == PW) {
+            it_piece = 0;
+            if (++it_reg == R) it_reg = 0;
+            if (++it_slot == NSLOT) {
+                it_slot = 0;
+                it_t += nstreams;
+                while (it_t >= tiles_per_b && it_b < p.B) {
+                    it_t -= tiles_per_b;
+                    ++it_b;
+                }
+            }
+        }
+    };
+#pragma unroll 1
+    for (int i = 0; i < D * PW; ++i) issue_piece();
+
+    float rs1[RT], rs2[RT];
+#pragma unroll
+    for (int t = 0; t < RT; ++t) rs1[t] = rs2[t] = 0.f;
+    int rs_b = -1;
+    auto flush_rowstats = [&]() {          // this wave's rows are its own: no cross-wave step
+        if (!p.rowstats || rs_b < 0) return;
+        const int l = opaque_lane();
+#pragma unroll
+        for (int t = 0; t < RT; ++t) {
+            const float a = rs1[t] + __shfl_xor(rs1[t], 32), b2 = rs2[t] + __shfl_xor(rs2[t], 32);
+            const int m = m_first + 32 * t + (l & 31);
+            if (l < 32 && m < p.M) {
+                atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2, (double)a);
+                atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2 + 1, (double)b2);
+            }
+            rs1[t] = rs2[t] = 0.f;
+        }
+    };
+
+    int q_reg = 0;                         // region of the slot being consumed
+    const uint32_t lds0 = lds_addr(lds);
+    int b = 0, tb = stream;                // tile being computed: batch item, tile inside it
+    while (tb >= tiles_per_b && b < p.B) {
+        tb -= tiles_per_b;
+        ++b;
+    }
+    while (b < p.B) {
+        const long long n0 = (long long)tb * WS_PN;
+        f32x16 acc[NPT][RT];
+#pragma unroll
+        for (int j = 0; j < NPT; ++j)
+#pragma unroll
+            for (int t = 0; t < RT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
+
+        auto run_phase = [&](auto PH) {
+            constexpr int phase = decltype(PH)::value;
+            constexpr int npieces = (G::cum(phase + 1) - G::cum(phase)) * PW;     // DMA pieces this phase issues
+            constexpr int pps = (npieces + KSP - 1) / KSP;                         // ... per k16 step
+            wait_vm<PW * (D + G::cum(phase) - phase - 1)>();   // my pieces of this slot have landed ...
+            block_sync();                                      // ... and everybody's; the regions issued into below are free
+            const uint32_t rb = lds0 + q_reg * REG_BYTES;
+            if (++q_reg == R) q_reg = 0;
+            // lane 16 G + 4 q + pp of a half reads, for k rows q (+ 4), the 4 pixels 16 (pp & 1) + 8 G + 4 (pp >> 1) ..
+            const int l = opaque_lane();
+            const int rowq = (l & 15) >> 2;
+            const int cl = 2 * (l & 1) + ((l >> 4) & 1), rot = 4 * ((rowq >> 1) & 1);
+            const uint32_t common = rb + 128 * (8 * (l >> 5) + rowq) + 8 * ((l >> 1) & 1);
+            const uint32_t a0 = common + 16 * ((cl + rot) & 7), a1 = common + 16 * ((4 + cl + rot) & 7);
+            u32x2 xr[2][NPT][2];
+            auto issue_reads = [&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if (WS_EXP(16)) return;
+                xr[s & 1][0][0] = lds_read_tr16<s * 2048>(a0);
+                xr[s & 1][0][1] = lds_read_tr16<s * 2048 + 512>(a0);
+                xr[s & 1][1][0] = lds_read_tr16<s * 2048>(a1);
+                xr[s & 1][1][1] = lds_read_tr16<s * 2048 + 512>(a1);
+            };
+            auto step = [&](auto S) {
+                constexpr int s = decltype(S)::value;
+                if constexpr (s + 1 < KSP) {
+                    issue_reads(std::integral_constant<int, s + 1>{});
+                    wait_lgkm<4>();
+                } else {
+                    wait_lgkm<0>();
+                }
+#pragma unroll
+                for (int j = 0; j < NPT; ++j) {
+                    if (WS_EXP(2)) continue;
+                    const u32x4 xx = {xr[s & 1][j][0][0], xr[s & 1][j][0][1], xr[s & 1][j][1][0], xr[s & 1][j][1][1]};
+                    const bf16x8 xfrag = __builtin_bit_cast(bf16x8, xx);
+#pragma unroll
+                    for (int t = 0; t < RT; ++t)
+                        acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfrag, wf[phase * KSP + s][t], acc[j][t], 0, 0, 0);
+                }
+                // DMA issue in the shadow of the matrix work
+#pragma unroll
+                for (int i = s * pps; i < (s + 1) * pps && i < npieces; ++i) issue_piece();
+            };
+            issue_reads(std::integral_constant<int, 0>{});
+            [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}), ...); }(
+                std::make_integer_sequence<int, KSP>{});
+        };
+        run_phase(std::integral_constant<int, 0>{});
+        if constexpr (NPH >= 2) run_phase(std::integral_constant<int, 1>{});
+        if constexpr (NPH >= 3) run_phase(std::integral_constant<int, 2>{});
+
+        // ---- second input: its NIN regions are the next slots of the ring ----
+        int in_reg0 = 0;
+        if constexpr (HAS_IN) {
+            wait_vm<PW * D>();
+            block_sync();
+            in_reg0 = q_reg;
+            q_reg += NIN;
+            if (q_reg >= R) q_reg -= R;
+        }
+
+        // ---- epilogue: every lane owns 16 consecutive pixels of one row per accumulator ----
+        if (p.rowstats && b != rs_b) {
+            flush_rowstats();
+            rs_b = b;
+        }
+        if (WS_EXP(1)) {
+#pragma unroll
+            for (int j = 0; j < NPT; ++j)
+#pragma unroll
+                for (int t = 0; t < RT; ++t) keep_alive(acc[j][t]);
+        } else {
+            const int l = opaque_lane();
+            const int ml = l & 31, h = l >> 5;
+            const long long px_l = n0 + 16 * h;                                 // + 32 j
+            const long long off_l = ((long long)b * p.M + m_first + ml) * p.P + px_l;     // + 32 t P + 32 j
+            unsigned short* yl = reinterpret_cast<unsigned short*>(p.y) + off_l;
+            unsigned short* al = reinterpret_cast<unsigned short*>(p.aux_out) + off_l;
+#pragma unroll
+            for (int j = 0; j < NPT; ++j) {
+                const bool ok0 = px_l + 32 * j < p.P, ok1 = px_l + 32 * j + 8 < p.P;
+#pragma unroll
+                for (int t = 0; t < RT; ++t) {
+                    const bool row_ok = m_first + 32 * t + ml < p.M;
+                    const long long off = (long long)(32 * t) * p.P + 32 * j;
+                    float v[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) v[r] = acc[j][t][r] + bias_t[t];
+                    auto store = [&](unsigned short* dst) {
+                        u32x4 lo, hi;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            lo[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
+                            hi[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
+                        }
+                        if (row_ok && ok0) *reinterpret_cast<u32x4*>(dst + off) = lo;
+                        if (row_ok && ok1) *reinterpret_cast<u32x4*>(dst + off + 8) = hi;
+                    };
+                    if (p.aux_out) store(al);
+                    if (p.gelu) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
+                    }
+                    if constexpr (HAS_IN) {
+                        const int mloc = wave * 32 * RT + 32 * t + ml;
+                        int reg = in_reg0 + mloc / IN_ROWS;
+                        if (reg >= R) reg -= R;
+                        const int rr = mloc % IN_ROWS;
+                        const uint32_t ib = lds0 + reg * REG_BYTES + 128 * rr;
+                        const u32x4 i0 = lds_read_b128<0>(ib + 16 * ((4 * j + 2 * h + (rr >> 1)) & 7));
+                        const u32x4 i1 = lds_read_b128<0>(ib + 16 * ((4 * j + 2 * h + 1 + (rr >> 1)) & 7));
+                        wait_lgkm<0>();
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const uint32_t w = i < 4 ? i0[i & 3] : i1[i & 3];
+                            const float e0 = __uint_as_float(w << 16), e1 = __uint_as_float(w & 0xFFFF0000u);
+                            if (mul_gelu_grad) {
+                                v[2 * i] *= gelu_grad_f(e0);
+                                v[2 * i + 1] *= gelu_grad_f(e1);
+                            } else {
+                                v[2 * i] += e0;
+                                v[2 * i + 1] += e1;
+                            }
+                        }
+                    }
+                    store(yl);
+                    if (p.rowstats) {
+                        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                        for (int g = 0; g < 2; ++g) {
+                            if (g == 0 ? ok0 : ok1) {
+#pragma unroll
+                                for (int i = 0; i < 8; i += 2) {
+                                    const uint32_t pk = pack_bf16x2(v[8 * g + i], v[8 * g + i + 1]);
+                                    const float a = __uint_as_float(pk << 16), c2 = __uint_as_float(pk & 0xFFFF0000u);
+                                    s1 += a + c2;
+                                    s2 = fmaf(a, a, fmaf(c2, c2, s2));
+                                }
+                            }
+                        }
+                        rs1[t] += s1;
+                        rs2[t] += s2;
+                    }
+                }
+            }
+        }
+        tb += nstreams;
+        while (tb >= tiles_per_b && b < p.B) {
+            tb -= tiles_per_b;
+            ++b;
+        }
+    }
+    flush_rowstats();
+    wait_vm0();      // nothing may be in flight into LDS when the workgroup's LDS is released
+}
+
+template <int KSP, int NPH, bool HAS_IN>
+static int pce_ws_launch(const PceParams& p, hipStream_t st, int ncu) {
+    using G = WsGeom<KSP, NPH, HAS_IN>;
+    static const bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pce_ws_kernel<KSP, NPH, HAS_IN>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
+        return true;
+    }();
+    (void)once;
+    const int unit = 8 * p.npass;                       // workgroups w and w + 8 (same XCD) share a tile sequence
+    long long grid = (long long)(ncu / unit) * unit;
+    if (grid < unit) grid = unit;
+    hipLaunchKernelGGL((pce_ws_kernel<KSP, NPH, HAS_IN>), dim3((unsigned)grid), dim3(WS_THREADS), G::LDS, st, p);
+    return 0;
+}
+
 // ---- weight image ----------------------------------------------------------------------------------------------
 // element (pass, k16 step ks, row tile rt, lane, j)  <-  A[m][k],  m = pass*64*TH + rt*32 + (lane & 31),
 // k = 16 ks + 8 (lane >> 5) + j;  A = W or W^T;  one slot = the 2 TH fragments of one k16 step; 32 zero elements at the end
@@ -704,6 +1076,15 @@ static bool pce_config(int M, int K, PceCfg* c) {
     return true;
 }
 static long long pce_image_core_bytes(const PceCfg& c) { return (long long)c.npass * c.NPH * c.KSP * 2 * c.TH * 1024; }
+
+static int pce_cu_count() {
+    static const int ncu = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n > 0 ? n : 256;
+    }();
+    return ncu;
+}
 
 template <int KSP, int NPH, int TH, bool HAS_IN>
 static int pce_launch(const PceParams& p, hipStream_t st) {
@@ -809,6 +1190,32 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
         p.dbg = pce_dbg_buffer();
         p.exp = pexp;
         bool done = false;
+        // weights resident in registers when they fit (K <= 384, 384-row halves): MK_PCE_WS=0 keeps the streaming kernel
+        const int use_ws = [] { const char* e = getenv("MK_PCE_WS"); return e ? atoi(e) : 0; }();   // 0 never (default), 1 where the microbenchmark says it pays, 2 wherever it fits
+        // (measured, tools/pce_bench.py, back-to-back launches: ahead of the streaming kernel for K > 128 -- 0.46 vs 0.50 ms for
+        // 384 -> 384 and 0.85 vs 0.94 for 384 -> 768 at 721 x 1440 -- but behind it where the output dominates (73 -> 384: 0.33
+        // vs 0.24, its 16-byte store pieces against 64-byte row segments) and, with a second input, on short launches (ring
+        // depth 5 instead of 9).  Inside the training step, where every launch follows a weight pack and starts cold, its
+        // fixed cost (288 KB of fragments per workgroup before the first MFMA) eats the gain: 15.0 vs 14.7 ms per step over
+        // the 56 launches, so the streaming kernel stays the default.)
+        const long long ws_tiles_per_cu = (P + WS_PN - 1) / WS_PN * batch / pce_cu_count();
+        const bool ws_pays = use_ws == 2 || (K > 128 && !((addend || aux_in) && ws_tiles_per_cu < 16));
+        if (use_ws && ws_pays && c.TH == 6 && K > 64 && K <= 384) {
+            PceParams w = p;
+            w.tiles_per_b = (P + WS_PN - 1) / WS_PN;
+            MK_REQUIRE(w.tiles_per_b * batch < 2147483647LL, "too many pixel tiles");
+            w.ntiles = w.tiles_per_b * batch;
+            const bool has_in = p.addend || p.aux_in;
+            const int ncu = pce_cu_count();
+#define MK_WS_CASE(COND, KSP_, NPH_)                                                      \
+            if (!done && (COND)) {                                                        \
+                if (has_in) pce_ws_launch<KSP_, NPH_, true>(w, st, ncu);                  \
+                else pce_ws_launch<KSP_, NPH_, false>(w, st, ncu);                        \
+                done = true;                                                              \
+            }
+            MK_WS_CASE(K <= 80, 5, 1) MK_WS_CASE(K <= 128, 8, 1) MK_WS_CASE(K <= 256, 8, 2) MK_WS_CASE(K <= 384, 8, 3)
+#undef MK_WS_CASE
+        }
 #define MK_PCE_CASE(KSP_, NPH_, TH_) \
         if (!done && c.KSP == KSP_ && c.NPH == NPH_ && c.TH == TH_) {                                         \
             if (p.addend || p.aux_in) pce_launch<KSP_, NPH_, TH_, true>(p, st);                               \

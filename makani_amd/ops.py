@@ -339,8 +339,9 @@ def conv1x1_wgrad_raw(gy, x3):
     b, o, p = gy.shape
     i = x3.shape[1]
     gw = torch.zeros(o, i, dtype=torch.float32, device=x3.device)
-    _lib.check(_lib.load().mk_conv1x1_wgrad(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, _stream()),
-               "mk_conv1x1_wgrad")
+    lib = _lib.load()
+    fn = lib.mk_conv1x1_wgrad if os.environ.get("MK_WGRAD", "blocks") != "os" else lib.mk_conv1x1_wgrad_os
+    _lib.check(fn(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, _stream()), "mk_conv1x1_wgrad")
     return gw
 
 

@@ -352,14 +352,15 @@ def test_instance_norm(dev, B, C, H, W, dtype, fuse):
 @pytest.mark.parametrize("B,O,I,P", [(1, 128, 128, 4096), (2, 73, 384, 33 * 64), (1, 768, 384, 240 * 480), (3, 5, 7, 24),
                                       (1, 384, 73, 16384 + 8),
                                       (1, 768, 384, 400008), (2, 384, 768, 200008)])   # large-block kernels (256x192 / 192x256)
-def test_conv1x1_wgrad(dev, B, O, I, P):
+@pytest.mark.parametrize("entry", ["mk_conv1x1_wgrad", "mk_conv1x1_wgrad_os"])
+def test_conv1x1_wgrad(dev, B, O, I, P, entry):
     from makani_amd import _lib, ops
     g = torch.Generator().manual_seed(9)
     gy = torch.randn(B, O, P, generator=g).to(torch.bfloat16)
     x = torch.randn(B, I, P, generator=g).to(torch.bfloat16)
     gyd, xd = gy.to(dev), x.to(dev)
     gw = torch.zeros(O, I, dtype=torch.float32, device=dev)
-    _lib.check(_lib.load().mk_conv1x1_wgrad(gyd.data_ptr(), xd.data_ptr(), gw.data_ptr(), B, O, I, P, ops._stream()))
+    _lib.check(getattr(_lib.load(), entry)(gyd.data_ptr(), xd.data_ptr(), gw.data_ptr(), B, O, I, P, ops._stream()))
     want = torch.einsum("bop,bip->oi", gy.double(), x.double())
     assert rel(gw.cpu().numpy(), want.numpy()) < 2e-6      # exact bf16 products, fp32 accumulation
 

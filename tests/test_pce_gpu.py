@@ -20,9 +20,18 @@ def _rel(a, b):
     return (torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double())).item()
 
 
+@pytest.fixture(params=["streaming", "stationary"], autouse=True)
+def engine_variant(request, monkeypatch):
+    """Every test runs on both kernels of the engine: MK_PCE_WS=0 keeps the weight-streaming kernel, 2 takes the
+    weight-stationary one wherever the shape fits it (64 < K <= 384, M > 128); the default picks by measured speed."""
+    monkeypatch.setenv("MK_PCE_WS", "0" if request.param == "streaming" else "2")
+    return request.param
+
+
 # (M, K, P, batch): production channel counts on small pixel counts; ragged pixel tiles (P % 128 != 0), partial row
 # tiles (73), two passes (768 rows), two K phases (768 -> 384), tiny test-net sizes
 SHAPES = [(384, 384, 1024, 1), (384, 384, 1000, 2), (768, 384, 520, 1), (384, 768, 776, 1), (384, 73, 640, 1),
+          (200, 130, 72, 2), (384, 256, 64 * 300 + 24, 2), (768, 100, 64 * 520, 1),
           (73, 384, 264, 3), (73, 73, 1048, 1), (16, 8, 2048, 2), (3, 16, 72, 1), (96, 40, 392, 1), (128, 200, 136, 1),
           (200, 500, 256, 1)]
 
@@ -42,7 +51,8 @@ def test_pce_plain_gemm(dev, M, K, P, B):
     assert torch.equal(yt, y)
 
 
-@pytest.mark.parametrize("M,K,P,B", [(384, 384, 1000, 2), (768, 384, 520, 1), (73, 384, 264, 3), (16, 8, 2048, 2)])
+@pytest.mark.parametrize("M,K,P,B", [(384, 384, 1000, 2), (768, 384, 520, 1), (73, 384, 264, 3), (16, 8, 2048, 2),
+                                     (384, 73, 64 * 280 + 8, 2), (300, 200, 64 * 600, 1)])
 def test_pce_epilogues(dev, M, K, P, B):
     from makani_amd import ops
     torch.manual_seed(11)
@@ -83,7 +93,7 @@ def test_pce_gelu_accuracy(dev):
 
 
 @pytest.mark.parametrize("M,K,P,B", [(384, 768, 1000, 2), (768, 384, 520, 3), (73, 384, 264, 3), (16, 8, 2048, 2),
-                                     (384, 384, 128 * 300 + 40, 2)])
+                                     (384, 384, 128 * 300 + 40, 2), (768, 384, 64 * 300 + 16, 2)])
 def test_pce_row_sums(dev, M, K, P, B):
     """The epilogue's by-product: per-row (sum, sum of squares) of the STORED output, with every epilogue variant; the
     last shape gives each workgroup several tiles and a batch boundary inside its tile sequence."""
