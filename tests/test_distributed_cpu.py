@@ -273,6 +273,71 @@ def _body_net(rank, world):
         assert err < 5e-5, (n, err)
 
 
+def _body_loss(rank, world):
+    """LossHandler under spatial parallelism (losses.py:149-157): shards in, the global loss and exact shard gradients out."""
+    from types import SimpleNamespace
+    from makani_amd.losses import LossHandler
+    from oracle import losses as ol
+    H, W, C = 33, 64, 3
+    params = SimpleNamespace(loss="absolute squared geometric l2", n_future=0, img_shape_x=H, img_shape_y=W, img_crop_shape_x=H,
+                             img_crop_shape_y=W, img_crop_offset_x=0, img_crop_offset_y=0, N_out_channels=C,
+                             channel_names=["a", "b", "c"], channel_weights="auto", model_grid_type="equiangular")
+    g = torch.Generator().manual_seed(8)
+    prd, tar = torch.randn(2, C, H, W, generator=g), torch.randn(2, C, H, W, generator=g)
+    handler = LossHandler(params)
+    handler.train()
+    pl = _shard(_shard(prd, 2, "h"), 3, "w").clone().requires_grad_(True)
+    loss = handler(pl, _shard(_shard(tar, 2, "h"), 3, "w"), None)
+    loss.backward()
+    q = ol.quad_weight("naive", (H, W), (H, W), (0, 0), normalize=True)
+    want = ol.geometric_lp_loss(prd.numpy(), tar.numpy(), np.full((1, C), 1.0 / C), q, p=2, absolute=True, squared=True)
+    assert abs(float(loss) - want) < 2e-6 * abs(want)
+    gfull = 2.0 * (prd - tar).double() * torch.from_numpy(q) / C
+    assert _rel(pl.grad, _shard(_shard(gfull.float(), 2, "h"), 3, "w")) < 1e-6
+
+
+def _body_ckpt(rank, world):
+    """Flexible checkpoint (trainer.py:971-1098): written under this layout, it holds full-size tensors equal to the
+    un-sharded model's, and loads back into the sharded model bit for bit."""
+    import tempfile
+    from makani_amd import checkpoint, comm
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from makani_amd.distributed import compute_split_shapes
+    from oracle import spectral as osp
+    torch.manual_seed(99)
+    kw = dict(inp_shape=(33, 64), out_shape=(33, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=6, num_layers=2,
+              pos_embed="direct")
+    ref = osp.SphericalFourierNeuralOperatorNet(**kw)
+    net = SphericalFourierNeuralOperatorNet(**kw)
+    full = dict(ref.named_parameters())
+    with torch.no_grad():                                      # the sharded model holds this rank's pieces of `ref`
+        for k, v in net.named_parameters():
+            w = full[k].detach()
+            for d, group in enumerate(getattr(v, "sharded_dims_mp", [])):
+                if group is not None and comm.get_size(group) > 1:
+                    w = torch.split(w, compute_split_shapes(w.shape[d], comm.get_size(group)), dim=d)[comm.get_rank(group)]
+            v.copy_(w)
+    path = os.path.join(tempfile.gettempdir(), f"mk_flex_{os.environ['MASTER_PORT']}_mp{{mp_rank}}.tar")
+    checkpoint.save_flexible_checkpoint(path, net, iters=7, epoch=3)
+    dist.barrier()
+    stored = torch.load(path.format(mp_rank=0), map_location="cpu", weights_only=False)
+    assert stored["iters"] == 7 and stored["epoch"] == 3 and list(stored["model_state"]) == [k for k, _ in net.named_parameters()]
+    for k, w in stored["model_state"].items():
+        assert w.shape == full[k].shape and torch.equal(w, full[k].detach()), k
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    with torch.no_grad():
+        for v in net.parameters():
+            v.zero_()
+    assert checkpoint.restore_flexible_checkpoint(path, net) == (7, 3)
+    for k, v in net.named_parameters():
+        assert torch.equal(v.detach(), before[k]), k
+    with pytest.raises(NotImplementedError):
+        checkpoint.restore_flexible_checkpoint(path, net, load_optimizer=True)
+    dist.barrier()
+    if rank == 0:
+        os.remove(path.format(mp_rank=0))
+
+
 def _body_ddp(rank, world):
     """The reference's wrapper (mpu/mappings.py:30-174 semantics): DistributedDataParallel(find_unused_parameters=False)
     with the gradient-reduction hook, two optimizer steps; the reduced gradients equal reduce_shared_gradients' ones."""
@@ -355,6 +420,15 @@ def test_h2(what):
 @pytest.mark.parametrize("what", ["groups", "sht", "net"])
 def test_h2_w2(what):
     _run(4, 2, 2, what)
+
+
+def test_loss_handler_gathers_spatial_shards():
+    _run(4, 2, 2, "loss")
+
+
+@pytest.mark.parametrize("hsize,wsize", [(2, 1), (2, 2)])
+def test_flexible_checkpoint(hsize, wsize):
+    _run(hsize * wsize, hsize, wsize, "ckpt")
 
 
 def test_data_parallel_times_h():

@@ -530,3 +530,24 @@ def test_conv_kernels_reject_misaligned_and_odd_sizes(dev):
     w = (torch.randn(O, I, device=dev) / I ** 0.5)
     y = ops.pce_gemm(xv, ops.pce_pack(w), O)
     assert rel(y.float().cpu().numpy(), (w.bfloat16().double() @ xv[0].double()).unsqueeze(0).cpu().numpy()) < 3e-3
+
+
+def test_geometric_l2_loss_fused_pass(dev):
+    """The absolute squared geometric L2 loss with uniform channel weights is one HIP pass (mk_wmse_*); it must agree with
+    the oracle and with the general torch path (non-uniform weights), values and gradients."""
+    from makani_amd.losses import GeometricLpLoss
+    from oracle import losses as ol
+    g = torch.Generator().manual_seed(12)
+    B, C, H, W = 2, 6, 48, 96
+    prd, tar = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    q = ol.quad_weight("legendre-gauss", (H, W), (H, W), (0, 0), normalize=True)
+    loss = GeometricLpLoss((H, W), (H, W), (0, 0), p=2, absolute=True, squared=True, quadrature_rule="legendre-gauss").to(dev)
+    for chw in (torch.full((1, C), 1.0 / C), torch.rand(1, C, generator=g)):
+        pd = prd.to(dev).requires_grad_(True)
+        out = loss(pd, tar.to(dev), chw.to(dev))
+        out.backward()
+        want = ol.geometric_lp_loss(prd.numpy(), tar.numpy(), chw.numpy(), q, p=2, absolute=True, squared=True)
+        assert abs(float(out) - want) < 5e-6 * abs(want)
+        gwant = 2.0 * (prd - tar).double() * torch.from_numpy(q) * chw.double().view(1, C, 1, 1)
+        assert rel(pd.grad.cpu().numpy(), gwant.numpy()) < 2e-6
+    assert loss._chw_uniform is None          # the second weight vector took the general path

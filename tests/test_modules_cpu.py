@@ -1,5 +1,9 @@
 """CPU tests of the host-side mirror: construction, state-dict parity with the reference's
 key list, parameter annotations, weight storage layout.  No kernel launches."""
+import math
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -84,3 +88,87 @@ def test_fft_variant_constructs():
                                           max_modes=(16, 16)))
     x = torch.randn(1, 4, 32, 64)
     assert net(x).shape == (1, 2, 32, 64)
+
+
+# --------------------------------------------------------------------------- losses (utils/losses.py, utils/grids.py)
+@pytest.mark.parametrize("rule", ["naive", "legendre-gauss", "clenshaw-curtiss"])
+@pytest.mark.parametrize("crop", [None, ((20, 48), (5, 8))])
+def test_grid_quadrature_against_oracle(rule, crop):
+    from makani_amd.losses import GridQuadrature
+    from oracle import losses as ol
+    shape = (33, 64)
+    cs, co = crop if crop else (None, (0, 0))
+    for normalize, pole in ((False, 0), (True, 2)):
+        q = GridQuadrature(rule, shape, crop_shape=cs, crop_offset=co, normalize=normalize, pole_mask=pole)
+        want = ol.quad_weight(rule, shape, cs, co, normalize, pole)
+        np.testing.assert_allclose(q.quad_weight[0, 0].double().numpy(), want, rtol=2e-6, atol=1e-12)
+    if crop is None and rule != "naive":
+        assert abs(float(GridQuadrature(rule, shape).quad_weight.double().sum()) - 4 * math.pi) < 1e-5    # area of the sphere
+
+
+@pytest.mark.parametrize("p,absolute,squared", [(2, False, False), (2, True, True), (2, True, False), (1, False, False),
+                                                (1, True, False), (2, False, True)])
+def test_geometric_lp_loss_against_oracle(p, absolute, squared):
+    from makani_amd.losses import GeometricLpLoss
+    from oracle import losses as ol
+    g = torch.Generator().manual_seed(4)
+    B, C, H, W = 2, 5, 33, 64
+    prd, tar = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
+    chw = torch.rand(1, C, generator=g)
+    loss = GeometricLpLoss((H, W), (H, W), (0, 0), p=p, absolute=absolute, squared=squared, quadrature_rule="legendre-gauss")
+    got = loss(prd, tar, chw)
+    q = ol.quad_weight("legendre-gauss", (H, W), (H, W), (0, 0), normalize=True)
+    want = ol.geometric_lp_loss(prd.numpy(), tar.numpy(), chw.numpy(), q, p=p, absolute=absolute, squared=squared)
+    assert abs(float(got) - want) < 2e-6 * max(1.0, abs(want))
+
+
+def test_loss_handler_parses_like_the_reference():
+    from types import SimpleNamespace
+    from makani_amd.losses import LossHandler
+    from oracle import losses as ol
+    H, W, C = 33, 64, 4
+    base = dict(n_future=0, img_shape_x=H, img_shape_y=W, img_crop_shape_x=H, img_crop_shape_y=W, img_crop_offset_x=0,
+                img_crop_offset_y=0, N_out_channels=C, channel_names=["u10m", "sst", "t2m", "z500"], channel_weights="auto",
+                model_grid_type="equiangular")
+    g = torch.Generator().manual_seed(1)
+    prd, tar = torch.randn(2, C, H, W, generator=g), torch.randn(2, C, H, W, generator=g)
+    for spec, (p, rule, absolute, squared, weighted) in {
+            "l2": (2, "naive", False, False, False), "geometric l2": (2, "naive", False, False, False),
+            "absolute squared geometric l2": (2, "naive", True, True, False), "weighted geometric l1": (1, "naive", False, False, True),
+            "pole-masked absolute l2": (2, "naive", True, False, False)}.items():
+        h = LossHandler(SimpleNamespace(loss=spec, **base))
+        h.train()
+        chw = np.ones(C)
+        if weighted:
+            chw[1] = 0.0                                          # "sst" is switched off (losses.py:63-65)
+        chw = (chw / chw.sum()).reshape(1, C)
+        q = ol.quad_weight(rule, (H, W), (H, W), (0, 0), normalize=True, pole_mask=1 if "pole-masked" in spec else 0)
+        want = ol.geometric_lp_loss(prd.numpy(), tar.numpy(), chw, q, p=p, absolute=absolute, squared=squared)
+        assert abs(float(h(prd, tar, None)) - want) < 2e-6 * max(1.0, abs(want)), spec
+    with pytest.raises(ValueError):
+        LossHandler(SimpleNamespace(loss="huber", **base))
+
+
+# --------------------------------------------------------------------------- registration (pyproject.toml:106-112)
+def test_entry_points_resolve():
+    import importlib
+    import tomli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "pyproject.toml"), "rb") as f:
+        eps = tomli.load(f)["project"]["entry-points"]["makani.models"]
+    assert set(eps) == {"SFNO_MI355X", "FNO_MI355X"}
+    for target in eps.values():
+        mod, name = target.split(":")
+        assert issubclass(getattr(importlib.import_module(mod), name), torch.nn.Module)
+
+
+def test_file_path_registration_like_model_registry():
+    """model_registry.py:63-79: 'path/to/file.py:Name' through spec_from_file_location, then instantiate."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("SphericalFourierNeuralOperatorNet", os.path.join(root, "sfno_mi355x.py"))
+    module = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(module)
+    net = module.SphericalFourierNeuralOperatorNet(inp_shape=(17, 32), out_shape=(17, 32), scale_factor=2, inp_chans=2,
+                                                   out_chans=2, embed_dim=4, num_layers=1)
+    assert isinstance(net, torch.nn.Module) and len(list(net.parameters())) > 0
