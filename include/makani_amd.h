@@ -245,20 +245,27 @@ int mk_conv1x1_fwd(const void* a, const void* x, const void* addend, void* y, in
  *   the backward pass);   v = gelu ? GELU(acc) : acc;   v *= GELU'(aux_in[b][m][p]) (optional: backward of the activation);
  *   y = v (+ addend[b][m][p]).
  * A comes pre-packed (mk_pce_pack) as the MFMA fragment image of W [M][K] (forward) or of W^T (data gradient).
- * x, y, addend, aux_* are bf16 [B][C][P], P a multiple of 8; K <= 768, and M <= 384 when K > 384; bias is fp32 (or NULL) with
- * M rounded up to a multiple of 384 readable entries (the epilogue loads it unconditionally); addend and aux_in are exclusive.
+ * x, y, addend, aux_* are bf16 [B][C][P], P a multiple of 8; K <= 768, and M <= 384 when K > 384; bias is fp32 [M]
+ * (or NULL); addend and aux_in are exclusive.
  * Replaces hipBLASLt's mm/addmm behind nn.Conv2d(.., 1) and the separate bias+GELU passes. */
 long long mk_pce_image_bytes(int M, int K);
 int mk_pce_pack(const void* w, int w_dtype /* 0 fp32, 1 bf16 */, int transpose, int M, int K, int ldw, void* img,
                 void* stream);
 int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const void* aux_in,
                 void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream);
-/* The same with the per-row sums of the stored output as a by-product: rowstats [B][M][2] (double) receives sum and sum of
- * squares over the pixels of every y row -- the statistics pass of the instance norm that follows an MLP (sfnonet.py:262-263)
- * and the bias gradient of a convolution (sum over pixels of the output gradient) without another pass over the field.
- * M <= 768; the buffer is zeroed by the call. */
-int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const void* aux_in,
-                   void* aux_out, int gelu, double* rowstats, int batch, int M, int K, long long P, void* stream);
+/* The same with two more seams to the instance norms around the convolutions (sfnonet.py:262-267):
+ *  - rowstats [B][M][2] (double, zeroed by the call; M <= 768) receives sum and sum of squares over the pixels of every
+ *    stored y row: the statistics pass of the norm that follows an MLP, and the bias gradient of a convolution (sum over
+ *    pixels of the output gradient), without another pass over the field;
+ *  - addend_affine [B][M][2] (float) makes the addend enter as a * addend + b per row: the APPLY pass of the instance norm
+ *    in front of a skip connection (coefficients from mk_instnorm_coeffs), folded into the skip convolution. */
+int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const float* addend_affine,
+                   const void* aux_in, void* aux_out, int gelu, double* rowstats, int batch, int M, int K, long long P,
+                   void* stream);
+/* Per-row coefficients of an instance norm from its row sums: stats[row] = (mean, rstd) (the form mk_instnorm_bwd takes),
+ * affine[row] = (rstd * weight[c], bias[c] - mean * rstd * weight[c]); count = elements per row (global, when sharded). */
+int mk_instnorm_coeffs(const double* sums, const float* weight, const float* bias, float* stats, float* affine, int rows,
+                       int C, long long count, float eps, void* stream);
 /* Profiling aid (tools/pce_stamps.py): with MK_PCE_DBG=1 in the environment the kernel records s_memtime stamps of
  * workgroup 0; this copies the 8 x 64 stamps of the last launch to the host. */
 int mk_pce_debug_stamps(unsigned long long* out512);

@@ -49,8 +49,11 @@ struct PceParams {
     const char* wimg;              // mk_pce_pack image
     const char* zeros;             // 64 zero bytes behind the image (source of masked DMA lanes)
     __hip_bfloat16* y;             // [B][M][P]
-    const float* bias;             // [M] or null
+    const float* bias;             // [nbias] floats, read at min(row, nbias - 1)
+    int nbias;
     const __hip_bfloat16* addend;  // [B][M][P] or null: y += addend
+    const float* aff;              // [B][M][2] or null: the addend enters as aff[..][0] * addend + aff[..][1] (a per-row affine map:
+                                   // the instance norm of the addend, applied here instead of in a pass of its own)
     const __hip_bfloat16* aux_in;  // [B][M][P] or null: y *= gelu'(aux_in)   (applied before the addend)
     __hip_bfloat16* aux_out;       // [B][M][P] or null: pre-activation (acc + bias) stored here
     double* rowstats;              // [B][M][2] or null: += (sum, sum of squares) over the pixels of the stored y rows
@@ -215,7 +218,7 @@ __device__ __forceinline__ u32x2 lds_read_b64(uint32_t addr) {
 template <int TH, bool HAS_IN>
 __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[TH], const EpiAddr& ea, int m_first, int m_local,
                                              long long tile_base /* b*M*P + n0 + 32 pg */, bool px_ok, int gmask,
-                                             float (&ts1)[TH], float (&ts2)[TH]) {
+                                             float (&ts1)[TH], float (&ts2)[TH], int row_base /* b*M */) {
     const unsigned short* in = reinterpret_cast<const unsigned short*>(p.aux_in ? p.aux_in : p.addend);
     constexpr bool has_in = HAS_IN;
     const bool mul_gelu_grad = p.aux_in != nullptr;
@@ -254,7 +257,24 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
     // the round trip of every store queued before it
     float bias_t[TH];
 #pragma unroll
-    for (int t = 0; t < TH; ++t) bias_t[t] = p.bias[m_first + 32 * t + m_local];   // always there (zeros if the layer has none)
+    for (int t = 0; t < TH; ++t) bias_t[t] = p.bias[min(m_first + 32 * t + m_local, p.nbias - 1)];   // always there (zeros if the layer has none); rows past M are never stored
+    // the addend's per-row affine map (identity without one), loaded with the bias for the same reason
+    float aff_a[TH], aff_b[TH];
+#pragma unroll
+    for (int t = 0; t < TH; ++t) {
+        aff_a[t] = 1.f;
+        aff_b[t] = 0.f;
+    }
+    if constexpr (has_in) {
+        if (p.aff) {
+#pragma unroll
+            for (int t = 0; t < TH; ++t) {
+                const float2 ab = *reinterpret_cast<const float2*>(p.aff + 2 * (long long)(row_base + min(m_first + 32 * t + m_local, p.M - 1)));
+                aff_a[t] = ab.x;
+                aff_b[t] = ab.y;
+            }
+        }
+    }
     if constexpr (has_in) fetch(0, pf[0]);
 #pragma unroll
     for (int t = 0; t < TH; ++t) {
@@ -288,7 +308,8 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
                     v[4 * g] *= gelu_grad_f(i0); v[4 * g + 1] *= gelu_grad_f(i1);
                     v[4 * g + 2] *= gelu_grad_f(i2); v[4 * g + 3] *= gelu_grad_f(i3);
                 } else {
-                    v[4 * g] += i0; v[4 * g + 1] += i1; v[4 * g + 2] += i2; v[4 * g + 3] += i3;
+                    v[4 * g] += fmaf(aff_a[t], i0, aff_b[t]); v[4 * g + 1] += fmaf(aff_a[t], i1, aff_b[t]);
+                    v[4 * g + 2] += fmaf(aff_a[t], i2, aff_b[t]); v[4 * g + 3] += fmaf(aff_a[t], i3, aff_b[t]);
                 }
             }
         }
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
 #pragma unroll
             for (int t = 0; t < TH; ++t) ts1[t] = ts2[t] = 0.f;
             pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.M * p.P + px0,
-                                     px0 + ea.px_lin < p.P, gmask, ts1, ts2);
+                                     px0 + ea.px_lin < p.P, gmask, ts1, ts2, b * p.M);
             if (p.rowstats) {
                 if (pass == 0) {
 #pragma unroll
@@ -738,7 +759,7 @@ __global__ __launch_bounds__(WS_THREADS, 1) void pce_ws_kernel(PceParams p) {
     const int m_first = half * WS_ROWS + wave * 32 * RT;
     float bias_t[RT];
 #pragma unroll
-    for (int t = 0; t < RT; ++t) bias_t[t] = p.bias[m_first + 32 * t + (lane & 31)];
+    for (int t = 0; t < RT; ++t) bias_t[t] = p.bias[min(m_first + 32 * t + (lane & 31), p.nbias - 1)];
 
     // ---- DMA issue side.  Slot sequence of a workgroup: (tile, slot 0 .. NSLOT-1), region = running slot index mod R.
     //      One piece = 8 rows x 64 px; wave w issues pieces w PW .. w PW + PW - 1 of a region, so its rows are
@@ -1141,12 +1162,12 @@ __global__ void pce_zero_kernel(double* p, long long n) {
 
 extern "C" int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend,
                            const void* aux_in, void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream) {
-    return mk_pce_gemm_ex(x, wimg, y, bias, addend, aux_in, aux_out, gelu, nullptr, batch, M, K, P, stream);
+    return mk_pce_gemm_ex(x, wimg, y, bias, addend, nullptr, aux_in, aux_out, gelu, nullptr, batch, M, K, P, stream);
 }
 
 extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const float* bias, const void* addend,
-                              const void* aux_in, void* aux_out, int gelu, double* rowstats, int batch, int M, int K,
-                              long long P, void* stream) {
+                              const float* addend_affine, const void* aux_in, void* aux_out, int gelu, double* rowstats,
+                              int batch, int M, int K, long long P, void* stream) {
     MK_REQUIRE(x && wimg && y, "null pointer");
     MK_REQUIRE(batch > 0 && M > 0 && K > 0 && P > 0, "bad sizes");
     MK_REQUIRE((P % 8) == 0, "P = H*W must be a multiple of 8 (16-byte row alignment)");
@@ -1155,6 +1176,8 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
     MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768; M <= 384 when K > 384)");
     static const int pexp = [] { const char* e = getenv("MK_PCE_EXP"); return e ? atoi(e) : 0; }();
     MK_REQUIRE(!(addend && aux_in), "addend and aux_in are exclusive");
+    MK_REQUIRE(!addend_affine || addend, "addend_affine needs an addend");
+    MK_REQUIRE(((uintptr_t)addend_affine & 7) == 0, "addend_affine must be 8-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     if (rowstats) {
         MK_REQUIRE(c.npass <= 2, "row statistics are built for M <= 768");
@@ -1174,7 +1197,9 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
         p.zeros = zeros;
         p.y = (__hip_bfloat16*)y;
         p.bias = bias ? bias : zero_bias;
+        p.nbias = bias ? M : 1024;
         p.addend = (const __hip_bfloat16*)addend;
+        p.aff = addend_affine;
         p.aux_in = (const __hip_bfloat16*)aux_in;
         p.aux_out = (__hip_bfloat16*)aux_out;
         p.rowstats = rowstats;
@@ -1200,7 +1225,7 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
         // the 56 launches, so the streaming kernel stays the default.)
         const long long ws_tiles_per_cu = (P + WS_PN - 1) / WS_PN * batch / pce_cu_count();
         const bool ws_pays = use_ws == 2 || (K > 128 && !((addend || aux_in) && ws_tiles_per_cu < 16));
-        if (use_ws && ws_pays && c.TH == 6 && K > 64 && K <= 384) {
+        if (use_ws && ws_pays && !addend_affine && c.TH == 6 && K > 64 && K <= 384) {
             PceParams w = p;
             w.tiles_per_b = (P + WS_PN - 1) / WS_PN;
             MK_REQUIRE(w.tiles_per_b * batch < 2147483647LL, "too many pixel tiles");

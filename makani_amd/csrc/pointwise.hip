@@ -371,6 +371,38 @@ extern "C" int mk_instnorm_fwd(const void* x, const float* weight, const float* 
     return mk_instnorm_fwd_ex(x, weight, bias, y, stats, workspace, dtype, rows, C, P, P, eps, fuse_gelu, 0, stream);
 }
 
+namespace {
+__global__ void instnorm_coeffs_kernel(const double* __restrict__ sums, const float* __restrict__ w, const float* __restrict__ b,
+                                       float* __restrict__ stats, float* __restrict__ affine, int rows, int C, double count,
+                                       float eps) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= rows) return;
+    const int c = row % C;
+    const double mean_d = sums[2 * row] / count;            // the arithmetic of instnorm_apply_kernel, once per row
+    double var_d = sums[2 * row + 1] / count - mean_d * mean_d;
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, rstd = (float)(1.0 / sqrt(var_d + (double)eps));
+    stats[2 * row] = mean;
+    stats[2 * row + 1] = rstd;
+    const float sc = rstd * (w ? w[c] : 1.f);
+    affine[2 * row] = sc;
+    affine[2 * row + 1] = (b ? b[c] : 0.f) - mean * sc;
+}
+}  // namespace
+
+// The instance norm of a field as a per-row affine map y = affine[row][0] * x + affine[row][1], from the row sums
+// (sum x, sum x^2; summed over the ranks that share a row when it is sharded) -- for a consumer that applies it while it
+// reads x (mk_pce_gemm_ex, addend_affine).  stats[row] = (mean, rstd) is what mk_instnorm_bwd_ex takes.
+extern "C" int mk_instnorm_coeffs(const double* sums, const float* weight, const float* bias, float* stats, float* affine,
+                                  int rows, int C, long long count, float eps, void* stream) {
+    MK_REQUIRE(sums && stats && affine, "null pointer");
+    MK_REQUIRE(rows > 0 && C > 0 && count > 0, "bad sizes");
+    hipLaunchKernelGGL(instnorm_coeffs_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, sums,
+                       weight, bias, stats, affine, rows, C, (double)count, eps);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
 // phases as in mk_instnorm_fwd_ex; the phase-1 sums (sum g', sum g' xhat per row) are also the LOCAL bias / weight
 // gradient contributions
 extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const float* weight,
@@ -418,30 +450,38 @@ namespace {
 template <typename T, bool BWD>
 __global__ __launch_bounds__(kT) void wmse_kernel(const T* __restrict__ pred, const float* __restrict__ tar,
                                                   const float* __restrict__ wrow, double* __restrict__ acc,
-                                                  const float* __restrict__ gloss, T* __restrict__ gpred, int H, int W,
-                                                  float scale) {
-    __shared__ float red[4];
-    const long long row = blockIdx.x;
-    const float wr = wrow[row % H];
-    const T* p = pred + row * W;
-    const float* t = tar + row * W;
-    float s = 0.f;
-    const float k = BWD ? 2.f * scale * gloss[0] * wr : 0.f;
-    for (int i = threadIdx.x * kE; i < W; i += kT * kE) {   // W is a multiple of 8
-        float v[kE], u[kE];
-        IO<T>::load(p + i, v);
-        IO<float>::load(t + i, u);
+                                                  const float* __restrict__ gloss, T* __restrict__ gpred, long long rows,
+                                                  int H, int W, float scale) {
+    // Forward: a workgroup walks rows blockIdx.x, + gridDim.x, ... and adds ONE double to the loss at the end (one
+    // atomic per row -- 52 k of them on one address at 73 x 721 -- serialised the whole pass: 0.64 ms for 455 MB).
+    __shared__ double redd[4];
+    double tot = 0.0;
+    for (long long row = blockIdx.x; row < rows; row += gridDim.x) {
+        const float wr = wrow[row % H];
+        const T* p = pred + row * W;
+        const float* t = tar + row * W;
+        float s = 0.f;
+        const float k = BWD ? 2.f * scale * gloss[0] * wr : 0.f;
+        for (int i = threadIdx.x * kE; i < W; i += kT * kE) {   // W is a multiple of 8
+            float v[kE], u[kE];
+            IO<T>::load(p + i, v);
+            IO<float>::load(t + i, u);
 #pragma unroll
-        for (int e = 0; e < kE; ++e) {
-            const float d = v[e] - u[e];
-            if (BWD) v[e] = k * d;
-            else s = fmaf(d, d, s);
+            for (int e = 0; e < kE; ++e) {
+                const float d = v[e] - u[e];
+                if (BWD) v[e] = k * d;
+                else s = fmaf(d, d, s);
+            }
+            if (BWD) IO<T>::store(gpred + row * W + i, v);
         }
-        if (BWD) IO<T>::store(gpred + row * W + i, v);
+        if (!BWD) tot += (double)(s * wr);
     }
     if (!BWD) {
-        const float tot = block_sum(s, red);
-        if (threadIdx.x == 0) atomicAdd(acc, (double)(tot * wr) * (double)scale);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+        if ((threadIdx.x & 63) == 0) redd[threadIdx.x >> 6] = tot;
+        __syncthreads();
+        if (threadIdx.x == 0) atomicAdd(acc, (redd[0] + redd[1] + redd[2] + redd[3]) * (double)scale);
     }
 }
 
@@ -455,12 +495,12 @@ extern "C" int mk_wmse_fwd(const void* pred, int dtype, const float* tar, const 
     hipStream_t st = (hipStream_t)stream;
     zero_doubles(loss, 1, st);
     if (dtype == 0)
-        hipLaunchKernelGGL((wmse_kernel<float, false>), dim3((unsigned)rows), dim3(kT), 0, st, (const float*)pred, tar, wrow,
-                           loss, (const float*)nullptr, (float*)nullptr, H, W, scale);
+        hipLaunchKernelGGL((wmse_kernel<float, false>), dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(kT), 0, st,
+                           (const float*)pred, tar, wrow, loss, (const float*)nullptr, (float*)nullptr, rows, H, W, scale);
     else
-        hipLaunchKernelGGL((wmse_kernel<__hip_bfloat16, false>), dim3((unsigned)rows), dim3(kT), 0, st,
-                           (const __hip_bfloat16*)pred, tar, wrow, loss, (const float*)nullptr, (__hip_bfloat16*)nullptr, H, W,
-                           scale);
+        hipLaunchKernelGGL((wmse_kernel<__hip_bfloat16, false>), dim3((unsigned)(rows < 4096 ? rows : 4096)), dim3(kT), 0, st,
+                           (const __hip_bfloat16*)pred, tar, wrow, loss, (const float*)nullptr, (__hip_bfloat16*)nullptr, rows,
+                           H, W, scale);
     MK_LAUNCH_CHECK();
     return 0;
 }
@@ -473,10 +513,10 @@ extern "C" int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const 
     hipStream_t st = (hipStream_t)stream;
     if (dtype == 0)
         hipLaunchKernelGGL((wmse_kernel<float, true>), dim3((unsigned)rows), dim3(kT), 0, st, (const float*)pred, tar, wrow,
-                           (double*)nullptr, gloss, (float*)gpred, H, W, scale);
+                           (double*)nullptr, gloss, (float*)gpred, rows, H, W, scale);
     else
         hipLaunchKernelGGL((wmse_kernel<__hip_bfloat16, true>), dim3((unsigned)rows), dim3(kT), 0, st,
-                           (const __hip_bfloat16*)pred, tar, wrow, (double*)nullptr, gloss, (__hip_bfloat16*)gpred, H, W, scale);
+                           (const __hip_bfloat16*)pred, tar, wrow, (double*)nullptr, gloss, (__hip_bfloat16*)gpred, rows, H, W, scale);
     MK_LAUNCH_CHECK();
     return 0;
 }

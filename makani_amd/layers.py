@@ -116,6 +116,80 @@ class _PceConv(torch.autograd.Function):
         return gx, gw, gb, (gy if has_addend else None)
 
 
+class _PceConvNormAdd(torch.autograd.Function):
+    """out[b] = W @ x[b] (+ bias) + instance_norm(z)[b]: the tail of an SFNO block (``sfnonet.py:262-267``: norm1 of the
+    MLP output, then the outer skip) as ONE engine launch.  The norm's statistics come with ``z`` from the launch that
+    produced it (``sums``: fp64 ``[B * C, 2]`` local row sums), a 2 us kernel turns them into per-row coefficients, and the
+    GEMM epilogue applies ``a * z + b`` while it adds the skip -- the normalised field is never written.  Backward: the
+    convolution's two gradients as in ``_PceConv``; the norm's from ``z``, the incoming gradient and the saved (mean, rstd)."""
+
+    @staticmethod
+    def forward(ctx, x3, w, bias, z4, sums, nw, nb, eps, group, count):
+        from . import ops
+        B, C, H, W = z4.shape
+        if group is not None:
+            torch.distributed.all_reduce(sums, group=group)
+        cnt = H * W if group is None else int(count)
+        wf = None if nw is None else nw.detach().float().contiguous()
+        bf = None if nb is None else nb.detach().float().contiguous()
+        stats, affine = ops.instance_norm_coeffs(sums, wf, bf, B * C, C, cnt, eps)
+        y = ops.pce_gemm(x3, ops.pce_pack(w), w.shape[0], bias=bias, addend=z4.view(B, C, H * W), addend_affine=affine)
+        empty = z4.new_empty(0, dtype=torch.float32)
+        ctx.save_for_backward(x3, w, z4, stats, wf if wf is not None else empty, bf if bf is not None else empty)
+        ctx.cfg = (None if bias is None else bias.dtype, None if nw is None else nw.dtype, None if nb is None else nb.dtype,
+                   group, cnt)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x3, w, z4, stats, wf, bf = ctx.saved_tensors
+        bias_dtype, nw_dtype, nb_dtype, group, cnt = ctx.cfg
+        B, C, H, W = z4.shape
+        gy = gy.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.pce_gemm(gy, ops.pce_pack(w, transpose=True), w.shape[1])
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv1x1_wgrad_raw(gy, x3).to(w.dtype)
+        if bias_dtype is not None and ctx.needs_input_grad[2]:
+            gb = _row_sums(gy).to(bias_dtype)
+        gz, gnw, gnb = ops.instance_norm_backward(z4, gy.view(B, C, H, W), stats, wf if nw_dtype is not None else None,
+                                                  bf if nb_dtype is not None else None, False, group, cnt)
+        return (gx, gw, gb, gz, None, gnw.to(nw_dtype) if nw_dtype is not None else None,
+                gnb.to(nb_dtype) if nb_dtype is not None else None, None, None, None)
+
+
+def conv_plus_instance_norm(conv, x, z, sums, norm):
+    """``conv(x) + norm(z)`` as one launch (``_PceConvNormAdd``) when the engine can take it, else None: ``conv`` a
+    ``Conv1x1``, ``norm`` an affine-or-not instance norm on the field's own statistics (single-GPU or spatially
+    distributed), ``z`` a bf16 field that came with its row sums ``sums``."""
+    from . import comm, ops
+    from .layer_norm import DistributedInstanceNorm2d
+    if sums is None or not isinstance(conv, Conv1x1) or z.dtype != torch.bfloat16 or not z.is_contiguous() or z.dim() != 4:
+        return None
+    if os.environ.get("MK_NORM_SKIP_FUSION", "1") == "0":
+        return None
+    group = count = None
+    if isinstance(norm, DistributedInstanceNorm2d):
+        if comm.get_size("spatial") > 1:
+            group, count = comm.get_group("spatial"), norm._global_count(z)
+        nw, nb = (norm.weight, norm.bias) if norm.affine else (None, None)
+    elif isinstance(norm, InstanceNorm2d) and not norm.track_running_stats:
+        nw, nb = norm.weight, norm.bias
+    else:
+        return None
+    x3 = _engine_field(x)
+    if x3 is None or not ops.pce_supported(conv.out_channels, conv.in_channels) or conv.out_channels != z.shape[1]:
+        return None
+    B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
+    if tuple(z.shape) != (B, conv.out_channels, H, W):
+        return None
+    with torch.autocast("cuda", enabled=False):
+        y = _PceConvNormAdd.apply(x3, conv.weight2d(), conv.bias, z, sums, nw, nb, norm.eps, group, count)
+    return y.view(B, conv.out_channels, H, W)
+
+
 class _PceMLP(torch.autograd.Function):
     """y = W2 @ gelu(W1 @ x + b1) (+ b2): the MLP / encoder / decoder of ``layers.py:86-216`` on bf16 ``[B, C, P]``
     fields.  Forward: two engine launches, bias + GELU in the epilogue of the first (which also keeps the

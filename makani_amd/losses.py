@@ -77,6 +77,7 @@ class GeometricLpLoss(nn.Module):
         self.absolute, self.squared, self.pole_mask = absolute, squared, pole_mask
         self.quadrature = GridQuadrature(quadrature_rule, img_shape=img_shape, crop_shape=crop_shape, crop_offset=crop_offset,
                                          normalize=True, pole_mask=pole_mask)
+        self.uniform_chw = None     # set by the owner of the channel weights when they are all equal (see _fused_abs_sq_l2)
 
     def _reduce(self, v):
         if not self.reduction:
@@ -91,15 +92,17 @@ class GeometricLpLoss(nn.Module):
         if not (prd.dim() == 4 and prd.is_contiguous() and tar.is_contiguous() and tar.dtype == torch.float32
                 and prd.dtype in (torch.float32, torch.bfloat16) and prd.shape[-1] % 8 == 0 and chw.numel() > 0):
             return None
-        key = (chw.data_ptr(), chw._version, tuple(chw.shape))
-        if getattr(self, "_chw_key", None) != key:          # one host read per weight tensor, not per step
-            c0 = chw.detach().reshape(-1).cpu()
-            self._chw_key = key
-            self._chw_uniform = float(c0[0]) if (c0.numel() == prd.shape[1] and bool((c0 == c0[0]).all())) else None
-        if self._chw_uniform is None:
+        # one weight for all channels?  Known on the host by whoever built the weights (LossHandler sets ``uniform_chw``);
+        # never read back from a device tensor here (that would be a synchronisation per step)
+        value = self.uniform_chw
+        if value is None and not chw.is_cuda:
+            c0 = chw.detach().reshape(-1)
+            if c0.numel() == prd.shape[1] and bool((c0 == c0[0]).all()):
+                value = float(c0[0])
+        if value is None:
             return None
         wrow = self.quadrature.quad_weight[0, 0, :, 0].contiguous()        # the weights do not vary along a latitude row
-        return ops.weighted_mse(prd, tar, wrow, self._chw_uniform)
+        return ops.weighted_mse(prd, tar, wrow, value)
 
     def abs(self, prd, tar, chw):
         fused = self._fused_abs_sq_l2(prd, tar, chw)
@@ -177,6 +180,11 @@ class LossHandler(nn.Module):
             raise ValueError(f"Unknown loss function: {self.loss_type}")
         multistep_weight = torch.ones(self.n_future + 1, dtype=torch.float32) / float(self.n_future + 1)
         self.register_buffer("multistep_weight", multistep_weight.reshape(-1, 1, 1, 1))
+        # host-side knowledge for the fused pass: the value of the channel weights if they are all equal (training / eval)
+        cw_train = (channel_weights * self.multistep_weight).reshape(-1)
+        cw_eval = channel_weights.reshape(-1)
+        self._uniform = {True: float(cw_train[0]) if bool((cw_train == cw_train[0]).all()) else None,
+                         False: float(cw_eval[0]) if bool((cw_eval == cw_eval[0]).all()) else None}
         self.do_gather_input = comm.get_size("spatial") > 1
         if self.do_gather_input:
             self.gather_shapes_h = compute_split_shapes(self.crop_shape[0], comm.get_size("h"))
@@ -194,4 +202,5 @@ class LossHandler(nn.Module):
             prd, tar = self._gather_input(prd), self._gather_input(tar)
         chw = self.channel_weights
         chw = (chw * self.multistep_weight).reshape(1, -1) if self.training else chw.reshape(1, -1)
+        self.loss_obj.uniform_chw = self._uniform[bool(self.training)]
         return self.loss_obj(prd, tar, chw)

@@ -399,10 +399,12 @@ def _zero_bias(device):
     return z
 
 
-def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False, want_row_sums=False):
+def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, gelu=False, want_row_sums=False,
+             addend_affine=None):
     """y[b] = epi(A @ x3[b]) on bf16 ``[B, K, P]`` fields (see ``mk_pce_gemm_ex``).  Returns ``y``, followed by ``pre``
     (the bf16 pre-activation ``A x + bias``) when ``want_pre`` and by the fp64 ``[B * M, 2]`` row sums (sum, sum of squares
-    over the pixels of ``y``) when ``want_row_sums``."""
+    over the pixels of ``y``) when ``want_row_sums``.  ``addend_affine`` (fp32 ``[B * M, 2]``) lets the addend enter as
+    ``a * addend + b`` per row (``instance_norm_coeffs``)."""
     _need_cuda(x3, wimg)
     assert x3.dim() == 3 and x3.is_contiguous() and x3.dtype == torch.bfloat16
     b, k, p = x3.shape
@@ -410,14 +412,18 @@ def pce_gemm(x3, wimg, m, bias=None, addend=None, aux_in=None, want_pre=False, g
         if t is not None:
             assert t.is_contiguous() and t.dtype == torch.bfloat16 and tuple(t.shape) == (b, m, p)
     bf = _zero_bias(x3.device)   # the epilogue loads a bias unconditionally: zeros for layers without one
-    if bias is not None:      # fp32, padded to whole passes of the kernel
-        bf = torch.zeros((m + 383) // 384 * 384, dtype=torch.float32, device=x3.device)
-        bf[:m] = bias.detach()
+    if bias is not None:      # fp32 [m]
+        bf = bias.detach().float().contiguous()
+        assert bf.numel() == m
     y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
     pre = torch.empty_like(y) if want_pre else None
     sums = torch.empty(b * m, 2, dtype=torch.float64, device=x3.device) if want_row_sums else None
+    if addend_affine is not None:
+        assert (addend is not None and addend_affine.dtype == torch.float32 and addend_affine.is_contiguous()
+                and addend_affine.numel() == 2 * b * m)
     _lib.check(_lib.load().mk_pce_gemm_ex(x3.data_ptr(), wimg.data_ptr(), y.data_ptr(), bf.data_ptr(),
                                           None if addend is None else addend.data_ptr(),
+                                          None if addend_affine is None else addend_affine.data_ptr(),
                                           None if aux_in is None else aux_in.data_ptr(),
                                           None if pre is None else pre.data_ptr(), int(bool(gelu)),
                                           None if sums is None else sums.data_ptr(), b, m, k, p, _stream()),
@@ -700,29 +706,48 @@ class _InstanceNorm(torch.autograd.Function):
     def backward(ctx, gy):
         x, stats, wf, bf = ctx.saved_tensors
         has_w, has_b, fuse, wdt, bdt, group, cnt = ctx.cfg
-        B, C, H, W = x.shape
-        gy = gy.contiguous()
-        gx = torch.empty_like(x)
-        ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
-        lib = _lib.load()
+        gx, gw, gb = instance_norm_backward(x, gy, stats, wf if has_w else None, bf if has_b else None, fuse, group, cnt)
+        return gx, gw.to(wdt) if has_w else None, gb.to(bdt) if has_b else None, None, None, None, None, None
 
-        def run(phase):
-            _lib.check(lib.mk_instnorm_bwd_ex(x.data_ptr(), gy.data_ptr(), stats.data_ptr(),
-                                              wf.data_ptr() if has_w else 0, bf.data_ptr() if has_b else 0,
-                                              gx.data_ptr(), ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, cnt, int(fuse),
-                                              phase, _stream()), "mk_instnorm_bwd_ex")
-        if group is None:
-            run(0)
-            local = ws
-        else:
-            run(1)
-            local = ws.clone()
-            torch.distributed.all_reduce(ws, group=group)
-            run(2)
-        sums = local.view(B, C, 2).sum(0)
-        gw = sums[:, 1].to(wdt) if has_w else None
-        gb = sums[:, 0].to(bdt) if has_b else None
-        return gx, gw, gb, None, None, None, None, None
+
+def instance_norm_backward(x, gy, stats, wf, bf, fuse_gelu=False, group=None, count=None):
+    """Backward of the (optionally GELU-fused) instance norm from its saved ``stats`` [B * C, 2] = (mean, rstd):
+    returns (gx, local weight-gradient sums [C] fp64, local bias-gradient sums [C] fp64)."""
+    B, C, H, W = x.shape
+    gy = gy.contiguous()
+    gx = torch.empty_like(x)
+    ws = torch.empty(B * C, 2, dtype=torch.float64, device=x.device)
+    lib = _lib.load()
+    cnt = H * W if group is None else int(count)
+
+    def run(phase):
+        _lib.check(lib.mk_instnorm_bwd_ex(x.data_ptr(), gy.data_ptr(), stats.data_ptr(),
+                                          wf.data_ptr() if wf is not None else 0, bf.data_ptr() if bf is not None else 0,
+                                          gx.data_ptr(), ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, cnt, int(fuse_gelu),
+                                          phase, _stream()), "mk_instnorm_bwd_ex")
+    if group is None:
+        run(0)
+        local = ws
+    else:
+        run(1)
+        local = ws.clone()
+        torch.distributed.all_reduce(ws, group=group)
+        run(2)
+    sums = local.view(B, C, 2).sum(0)
+    return gx, sums[:, 1], sums[:, 0]
+
+
+def instance_norm_coeffs(sums, weight, bias, rows, channels, count, eps):
+    """Row sums fp64 [rows, 2] (global when sharded) -> (stats, affine), both fp32 [rows, 2]: (mean, rstd) and the affine
+    map (a, b) with norm(x) = a * x + b (``mk_instnorm_coeffs``)."""
+    _need_cuda(sums)
+    assert sums.dtype == torch.float64 and sums.is_contiguous() and sums.numel() == 2 * rows
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=sums.device)
+    affine = torch.empty(rows, 2, dtype=torch.float32, device=sums.device)
+    _lib.check(_lib.load().mk_instnorm_coeffs(sums.data_ptr(), 0 if weight is None else weight.data_ptr(),
+                                              0 if bias is None else bias.data_ptr(), stats.data_ptr(), affine.data_ptr(),
+                                              rows, channels, int(count), float(eps), _stream()), "mk_instnorm_coeffs")
+    return stats, affine
 
 
 class _WeightedMSE(torch.autograd.Function):

@@ -26,7 +26,8 @@ from torch.utils.checkpoint import checkpoint
 from . import comm
 from .distributed import DistributedInverseRealSHT, DistributedRealSHT
 from .layer_norm import DistributedInstanceNorm2d
-from .layers import Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _is_exact_gelu
+from .layers import (Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _is_exact_gelu,
+                     conv_plus_instance_norm)
 from .sht import InverseRealSHT, RealSHT
 from .spectral_convolution import FactorizedSpectralConv, SpectralConv
 
@@ -133,8 +134,13 @@ class FourierNeuralOperatorBlock(nn.Module):
                 x, sums = self.mlp(x, skip_last_bias=self._removes_channel_constants(self.norm1), want_row_sums=True)
             else:
                 x = self.mlp(x, skip_last_bias=self._removes_channel_constants(self.norm1))
-        x = self.drop_path(self.norm1(x, row_sums=sums) if sums is not None else self.norm1(x))
         outer = getattr(self, "outer_skip", None)
+        if sums is not None and isinstance(self.drop_path, nn.Identity) and not hasattr(self, "act_layer1"):
+            # norm1 + outer skip: the norm's apply pass rides in the epilogue of the skip convolution
+            y = conv_plus_instance_norm(outer, residual, x, sums, self.norm1)
+            if y is not None:
+                return y
+        x = self.drop_path(self.norm1(x, row_sums=sums) if sums is not None else self.norm1(x))
         if isinstance(outer, Conv1x1):
             x = outer(residual, addend=x)                     # skip add folded into the GEMM epilogue
         elif outer is not None:

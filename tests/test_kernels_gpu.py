@@ -542,12 +542,13 @@ def test_geometric_l2_loss_fused_pass(dev):
     prd, tar = torch.randn(B, C, H, W, generator=g), torch.randn(B, C, H, W, generator=g)
     q = ol.quad_weight("legendre-gauss", (H, W), (H, W), (0, 0), normalize=True)
     loss = GeometricLpLoss((H, W), (H, W), (0, 0), p=2, absolute=True, squared=True, quadrature_rule="legendre-gauss").to(dev)
-    for chw in (torch.full((1, C), 1.0 / C), torch.rand(1, C, generator=g)):
+    for chw, uniform in ((torch.full((1, C), 1.0 / C), 1.0 / C), (torch.rand(1, C, generator=g), None)):
+        loss.uniform_chw = uniform             # what LossHandler knows on the host; None = general torch path
         pd = prd.to(dev).requires_grad_(True)
         out = loss(pd, tar.to(dev), chw.to(dev))
         out.backward()
+        assert (type(out.grad_fn).__name__ == "_WeightedMSEBackward") == (uniform is not None)
         want = ol.geometric_lp_loss(prd.numpy(), tar.numpy(), chw.numpy(), q, p=2, absolute=True, squared=True)
         assert abs(float(out) - want) < 5e-6 * abs(want)
         gwant = 2.0 * (prd - tar).double() * torch.from_numpy(q) * chw.double().view(1, C, 1, 1)
         assert rel(pd.grad.cpu().numpy(), gwant.numpy()) < 2e-6
-    assert loss._chw_uniform is None          # the second weight vector took the general path

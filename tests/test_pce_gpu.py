@@ -124,3 +124,48 @@ def test_instance_norm_with_given_sums(dev):
     a = ops.instance_norm(y.view(B, C, H, W), g, b, 1e-5)
     c = ops.instance_norm(y.view(B, C, H, W), g, b, 1e-5, row_sums=sums)
     assert _rel(c, a) < 1e-5
+
+
+@pytest.mark.parametrize("M,K,P,B", [(384, 384, 1000, 2), (73, 40, 264, 3), (768, 384, 520, 1)])
+def test_pce_addend_affine(dev, M, K, P, B):
+    """The addend enters as a[row] * addend + b[row]: the apply pass of an instance norm folded into the epilogue."""
+    from makani_amd import ops
+    torch.manual_seed(3)
+    w = (torch.randn(M, K) / math.sqrt(K)).to(dev)
+    x = torch.randn(B, K, P, device=dev).bfloat16()
+    add = torch.randn(B, M, P, device=dev).bfloat16()
+    aff = torch.randn(B * M, 2, device=dev)
+    y = ops.pce_gemm(x, ops.pce_pack(w), M, addend=add, addend_affine=aff)
+    ref = (torch.matmul(w.bfloat16().double(), x.double())
+           + aff[:, 0].double().view(B, M, 1) * add.double() + aff[:, 1].double().view(B, M, 1))
+    assert _rel(y, ref) < 3e-3
+
+
+def test_conv_plus_instance_norm_node(dev):
+    """conv(x) + instance_norm(z) as one launch: values and all five gradients against the torch composition (fp64)."""
+    from makani_amd import ops
+    from makani_amd.layers import Conv1x1, InstanceNorm2d, conv_plus_instance_norm
+    torch.manual_seed(21)
+    B, C, H, W = 2, 48, 20, 40
+    conv = Conv1x1(C, C, bias=False).to(dev)
+    norm = InstanceNorm2d(C, affine=True).to(dev)
+    with torch.no_grad():
+        norm.weight.copy_(torch.rand(C) + 0.5)
+        norm.bias.copy_(torch.randn(C))
+    x = torch.randn(B, C, H, W, device=dev).bfloat16().requires_grad_(True)
+    src = torch.randn(B, 16, H * W, device=dev).bfloat16()
+    z3, sums = ops.pce_gemm(src, ops.pce_pack(torch.randn(C, 16, device=dev) / 4), C, want_row_sums=True)
+    z = z3.view(B, C, H, W).requires_grad_(True)
+    y = conv_plus_instance_norm(conv, x, z, sums, norm)
+    assert y is not None and y.dtype == torch.bfloat16
+    gy = torch.randn_like(y)
+    y.backward(gy)
+    xd, zd = x.detach().double().requires_grad_(True), z.detach().double().requires_grad_(True)
+    wd = conv.weight.detach().bfloat16().double().requires_grad_(True)
+    nwd, nbd = norm.weight.detach().double().requires_grad_(True), norm.bias.detach().double().requires_grad_(True)
+    yd = torch.nn.functional.conv2d(xd, wd) + torch.nn.functional.instance_norm(zd, weight=nwd, bias=nbd, eps=norm.eps)
+    yd.backward(gy.double())
+    assert _rel(y, yd) < 4e-3
+    assert _rel(x.grad, xd.grad) < 4e-3 and _rel(z.grad, zd.grad) < 1e-2
+    assert _rel(conv.weight.grad, wd.grad) < 1e-3
+    assert _rel(norm.weight.grad, nwd.grad) < 1e-3 and _rel(norm.bias.grad, nbd.grad) < 1e-3
