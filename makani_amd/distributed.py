@@ -14,6 +14,8 @@ Fourier/spectral intermediates stay in the private channels-last layouts
 (``[M, K, B, C]`` / ``[L, M, B, C]``), so the channel split is a split of the
 contiguous axis.
 """
+import math
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -263,3 +265,66 @@ class DistributedInverseRealSHT(_DistSHTBase):
         B, C = x.shape[:2]
         c = ops.spec_pack(x.reshape(B * C, self.lmax_local, self.mmax_local).contiguous(), self.l_off, self.m_off)
         return self.inverse_packed(c, B)
+
+
+# ----------------------------------------------------------------------------
+# distributed planar transforms (the FNO variant of the network: spectral_transform="fft" under spatial parallelism)
+# ----------------------------------------------------------------------------
+class _DistFFT2Base(nn.Module):
+    """Sizes and shard shapes of ``makani/mpu/layers.py:38-66,105-133`` (same attribute names)."""
+
+    def __init__(self, nlat, nlon, lmax=None, mmax=None):
+        super().__init__()
+        self.comm_size_h, self.comm_size_w = comm.get_size("h"), comm.get_size("w")
+        self.comm_rank_w = comm.get_rank("w")
+        self.nlat, self.nlon = nlat, nlon
+        self.lmax = min(lmax or self.nlat, self.nlat)
+        self.mmax = min(mmax or self.nlon // 2 + 1, self.nlon // 2 + 1)
+        self.lmax_high, self.lmax_low = math.ceil(self.lmax / 2), math.floor(self.lmax / 2)
+        self.lat_shapes = compute_split_shapes(self.nlat, self.comm_size_h)
+        self.lon_shapes = compute_split_shapes(self.nlon, self.comm_size_w)
+        self.l_shapes = compute_split_shapes(self.lmax, self.comm_size_h)
+        self.m_shapes = compute_split_shapes(self.mmax, self.comm_size_w)
+
+
+class DistributedRealFFT2(_DistFFT2Base):
+    """``mpu/layers.py:38-100``: x [B, C, H/h, W/w] real -> [B, C, lmax/h, mmax/w] complex, ``rfft2(norm="ortho")`` with the
+    two axes made local one after the other by channel <-> axis transposes (one packed all-to-all each; the local FFTs are
+    torch.fft -- the planar transform is not on the SFNO hot path)."""
+
+    def forward(self, x):
+        num_chans = x.shape[1]
+        if self.comm_size_w > 1:                                              # w local, channels split
+            x = distributed_transpose_azimuth.apply(x, (1, -1), self.lon_shapes)
+        x = torch.fft.rfft(x, n=self.nlon, dim=-1, norm="ortho")[..., :self.mmax].contiguous()
+        if self.comm_size_w > 1:                                              # m split, channels local
+            x = distributed_transpose_azimuth.apply(x, (-1, 1), compute_split_shapes(num_chans, self.comm_size_w))
+        if self.comm_size_h > 1:                                              # h local, channels split
+            x = distributed_transpose_polar.apply(x, (1, -2), self.lat_shapes)
+        x = torch.fft.fft(x, n=self.nlat, dim=-2, norm="ortho")
+        x = torch.cat([x[..., :self.lmax_high, :], x[..., -self.lmax_low:, :]], dim=-2)
+        if self.comm_size_h > 1:                                              # l split, channels local
+            x = distributed_transpose_polar.apply(x, (-2, 1), compute_split_shapes(num_chans, self.comm_size_h))
+        return x
+
+
+class DistributedInverseRealFFT2(_DistFFT2Base):
+    """``mpu/layers.py:103-169``: the inverse of the above (zero padding between the high and low latitude modes when
+    ``lmax < nlat``)."""
+
+    def forward(self, x):
+        num_chans = x.shape[1]
+        if self.comm_size_h > 1:                                              # l local, channels split
+            x = distributed_transpose_polar.apply(x, (1, -2), self.l_shapes)
+        if self.lmax < self.nlat:
+            xh, xl = x[..., :self.lmax_high, :], x[..., -self.lmax_low:, :]
+            x = torch.cat([torch.nn.functional.pad(xh, (0, 0, 0, self.nlat - self.lmax)), xl], dim=-2)
+        x = torch.fft.ifft(x, n=self.nlat, dim=-2, norm="ortho")
+        if self.comm_size_h > 1:                                              # h split, channels local
+            x = distributed_transpose_polar.apply(x, (-2, 1), compute_split_shapes(num_chans, self.comm_size_h))
+        if self.comm_size_w > 1:                                              # m local, channels split
+            x = distributed_transpose_azimuth.apply(x, (1, -1), self.m_shapes)
+        x = torch.fft.irfft(x, n=self.nlon, dim=-1, norm="ortho")
+        if self.comm_size_w > 1:                                              # w split, channels local
+            x = distributed_transpose_azimuth.apply(x, (-1, 1), compute_split_shapes(num_chans, self.comm_size_w))
+        return x

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 from . import comm
-from .distributed import DistributedInverseRealSHT, DistributedRealSHT
+from .distributed import DistributedInverseRealFFT2, DistributedInverseRealSHT, DistributedRealFFT2, DistributedRealSHT
 from .layer_norm import DistributedInstanceNorm2d
 from .layers import (Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _is_exact_gelu,
                      conv_plus_instance_norm)
@@ -228,9 +228,7 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             fwd, inv = (DistributedRealSHT, DistributedInverseRealSHT) if distributed else (RealSHT, InverseRealSHT)
             outer, inner = dict(grid=model_grid_type, **modes), dict(grid=sht_grid_type, **modes)
         elif spectral_transform == "fft":
-            if distributed:
-                raise NotImplementedError("distributed planar FFT (mpu/layers.py:38-169) is outside the built hot path")
-            fwd, inv = RealFFT2, InverseRealFFT2
+            fwd, inv = (DistributedRealFFT2, DistributedInverseRealFFT2) if distributed else (RealFFT2, InverseRealFFT2)
             outer = inner = modes
         else:
             raise ValueError("Unknown spectral transform")

@@ -21,7 +21,7 @@ import torch.nn as nn
 
 from . import comm, ops
 from .contractions import get_contract_fun
-from .distributed import DistributedInverseRealSHT, DistributedRealSHT
+from .distributed import DistributedInverseRealFFT2, DistributedInverseRealSHT, DistributedRealSHT
 from .sht import InverseRealSHT, RealSHT
 
 
@@ -52,13 +52,16 @@ class SpectralConv(nn.Module):
         if not self.separable:
             weight_shape += [out_channels]
 
-        self._distributed = isinstance(self.inverse_transform, DistributedInverseRealSHT)
+        # spectral_convolution.py:59-75: a distributed transform (SHT or planar FFT) exposes its shard shapes
+        self._distributed = isinstance(self.inverse_transform, (DistributedInverseRealSHT, DistributedInverseRealFFT2))
         if self._distributed:
-            self.modes_lat_local = self.inverse_transform.l_shapes[comm.get_rank("h")]
-            self.modes_lon_local = self.inverse_transform.m_shapes[comm.get_rank("w")]
-            self.nlat_local = self.inverse_transform.lat_shapes[comm.get_rank("h")]
-            self.nlon_local = self.inverse_transform.lon_shapes[comm.get_rank("w")]
-            self.l_off, self.m_off = self.inverse_transform.l_off, self.inverse_transform.m_off
+            hr, wr = comm.get_rank("h"), comm.get_rank("w")
+            self.modes_lat_local = self.inverse_transform.l_shapes[hr]
+            self.modes_lon_local = self.inverse_transform.m_shapes[wr]
+            self.nlat_local = self.inverse_transform.lat_shapes[hr]
+            self.nlon_local = self.inverse_transform.lon_shapes[wr]
+            self.l_off = sum(self.inverse_transform.l_shapes[:hr])
+            self.m_off = sum(self.inverse_transform.m_shapes[:wr])
         else:
             self.modes_lat_local = self.modes_lat
             self.modes_lon_local = self.modes_lon
