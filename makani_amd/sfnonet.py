@@ -12,8 +12,8 @@ pixel-column engine, the skip convolution with the norm output as its epilogue a
 
 Spatial model parallelism (``comm.get_size("spatial") > 1``) selects the distributed transforms and
 ``DistributedInstanceNorm2d`` where the reference does (sfnonet.py:375-377, 528-533).  Channel
-("matmul") parallelism, ``layer_norm`` and the non-linear (attention) filter are outside the built hot
-path and raise.
+("matmul") parallelism and ``layer_norm`` are outside the built hot path and raise; the non-linear (attention)
+filter runs on the HIP transforms with a torch channel MLP in between (``spectral_convolution.SpectralAttention``).
 """
 import math
 from functools import partial
@@ -29,7 +29,7 @@ from .layer_norm import DistributedInstanceNorm2d
 from .layers import (Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _is_exact_gelu,
                      conv_plus_instance_norm)
 from .sht import InverseRealSHT, RealSHT
-from .spectral_convolution import FactorizedSpectralConv, SpectralConv
+from .spectral_convolution import FactorizedSpectralConv, SpectralAttention, SpectralConv
 
 _ACTIVATIONS = {"relu": nn.ReLU, "gelu": nn.GELU, "silu": nn.SiLU}
 
@@ -60,10 +60,14 @@ class SpectralFilterLayer(nn.Module):
                  hidden_size_factor=1, factorization=None, rank=1.0, separable=False, complex_activation="real",
                  spectral_layers=1, bias=False, drop_rate=0.0, gain=1.0):
         super().__init__()
-        if filter_type != "linear":
-            raise NotImplementedError("only filter_type='linear' is built (SpectralAttention is outside the hot path)")
         common = dict(operator_type=operator_type, separable=separable, bias=bias, gain=gain)
-        if factorization is None:
+        if filter_type == "non-linear":
+            self.filter = SpectralAttention(forward_transform, inverse_transform, embed_dim, embed_dim, operator_type=operator_type,
+                                            hidden_size_factor=hidden_size_factor, complex_activation=complex_activation,
+                                            spectral_layers=spectral_layers, drop_rate=drop_rate, bias=bias, gain=gain)
+        elif filter_type != "linear":
+            raise NotImplementedError
+        elif factorization is None:
             self.filter = SpectralConv(forward_transform, inverse_transform, embed_dim, embed_dim, **common)
         else:
             self.filter = FactorizedSpectralConv(forward_transform, inverse_transform, embed_dim, embed_dim, rank=rank,

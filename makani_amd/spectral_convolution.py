@@ -237,3 +237,103 @@ class FactorizedSpectralConv(SpectralConv):
         if hasattr(self, "bias"):
             x = x + self.bias
         return x.to(dtype=dtype), residual
+
+
+class ComplexReLU(nn.Module):
+    """``makani/models/common/activations.py:20-67``: (leaky) ReLU variants for complex tensors; modes ``cartesian``,
+    ``modulus`` (learned bias on |z|), ``halfplane`` (learned angle), ``real`` (acts on the real part only)."""
+
+    def __init__(self, negative_slope=0.0, mode="real", bias_shape=None, scale=1.0):
+        super().__init__()
+        self.mode = mode
+        if self.mode in ("modulus", "halfplane"):
+            self.bias = nn.Parameter(scale * torch.ones(bias_shape if bias_shape is not None else (1,), dtype=torch.float32))
+        else:
+            self.bias = 0
+        self.negative_slope = negative_slope
+        self.act = nn.LeakyReLU(negative_slope=negative_slope)
+
+    def forward(self, z):
+        if self.mode == "cartesian":
+            return torch.view_as_complex(self.act(torch.view_as_real(z)))
+        if self.mode == "modulus":
+            zabs = torch.sqrt(torch.square(z.real) + torch.square(z.imag))
+            return torch.where(zabs + self.bias > 0, (zabs + self.bias) * z / zabs, 0.0)
+        if self.mode == "halfplane":
+            angle = torch.angle(z) - self.bias
+            return torch.where(torch.logical_and(0.0 <= angle, angle < torch.pi / 2.0), z, self.negative_slope * z)
+        if self.mode == "real":
+            zr = torch.view_as_real(z)
+            return torch.view_as_complex(torch.stack([self.act(zr[..., 0]), zr[..., 1]], dim=-1))
+        raise NotImplementedError
+
+
+class SpectralAttention(nn.Module):
+    """The non-linear filter (``filter_type="non-linear"``; spectral_convolution.py:268-405): forward transform, a small
+    complex MLP over the channels of every spectral coefficient (``spectral_layers`` layers with ``ComplexReLU``, then
+    ``wout``), inverse transform.  Constructor arguments, parameter names (``w.N``, ``b.N``, ``wout``, ``activations.N.bias``)
+    and shapes are the reference's; ``operator_type`` is ``"diagonal"`` (one weight for all modes) or ``"l-dependant"`` (one
+    per degree l), anything else raises ``ValueError`` like the reference (so the network default ``"dhconv"`` does).
+
+    Deviation, documented: the reference's ``forward_mlp`` hands the ``view_as_real`` 5-D tensor to a 4-index einsum
+    (spectral_convolution.py:367-374 with contractions.py:49-54) and cannot run; the arithmetic here is the evident intent
+    -- the same einsums on the complex tensor.  No reference fixture can exist: parity of this class is unpinned.  The
+    transforms are the HIP SHT of this package; the channel MLP itself is a handful of torch complex matmuls (it is not on
+    the path the benchmark config takes).
+    """
+
+    def __init__(self, forward_transform, inverse_transform, in_channels, out_channels, operator_type="diagonal",
+                 hidden_size_factor=2, complex_activation="real", bias=False, spectral_layers=1, drop_rate=0.0, gain=1.0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.operator_type, self.spectral_layers = operator_type, spectral_layers
+        self.modes_lat, self.modes_lon = forward_transform.lmax, forward_transform.mmax
+        self.forward_transform, self.inverse_transform = forward_transform, inverse_transform
+        self.scale_residual = ((forward_transform.nlat != inverse_transform.nlat) or (forward_transform.nlon != inverse_transform.nlon)
+                               or (forward_transform.grid != inverse_transform.grid))
+        assert inverse_transform.lmax == self.modes_lat
+        assert inverse_transform.mmax == self.modes_lon
+        hidden = int(hidden_size_factor * in_channels)
+        if operator_type == "diagonal":
+            lead = ()
+            self._eq = "bixy,io->boxy"
+        elif operator_type == "l-dependant":
+            lead = (self.modes_lat,)
+            self._eq = "bixy,xio->boxy"
+        else:
+            raise ValueError("Unknown operator type")
+        w = [math.sqrt(2.0 / in_channels) * torch.randn(*lead, in_channels, hidden, dtype=torch.complex64)]
+        for _ in range(1, spectral_layers):
+            w.append(math.sqrt(2.0 / hidden) * torch.randn(*lead, hidden, hidden, dtype=torch.complex64))
+        self.w = nn.ParameterList([nn.Parameter(t) for t in w])
+        scale = math.sqrt(gain / in_channels)
+        if bias:
+            self.b = nn.ParameterList([nn.Parameter(scale * torch.randn(hidden, 1, 1, dtype=torch.complex64))
+                                       for _ in range(spectral_layers)])
+        self.wout = nn.Parameter(scale * torch.randn(*lead, hidden, out_channels, dtype=torch.complex64))
+        self.activations = nn.ModuleList([ComplexReLU(mode=complex_activation, bias_shape=(hidden, 1, 1), scale=scale)
+                                          for _ in range(spectral_layers)])
+        self.drop = nn.Dropout(drop_rate) if drop_rate > 0.0 else nn.Identity()
+
+    def forward_mlp(self, x):
+        for layer in range(self.spectral_layers):
+            x = torch.einsum(self._eq, x, self.w[layer])
+            if hasattr(self, "b"):
+                x = x + self.b[layer]
+            x = self.activations[layer](x)
+            if not isinstance(self.drop, nn.Identity):
+                x = torch.view_as_complex(self.drop(torch.view_as_real(x)))
+        return torch.einsum(self._eq, x, self.wout)
+
+    def forward(self, x):
+        dtype = x.dtype
+        residual = x
+        x = x.to(torch.float32)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x = self.forward_transform(x)
+            if self.scale_residual:
+                residual = self.inverse_transform(x).to(dtype)
+        x = self.forward_mlp(x)
+        with torch.autocast(device_type=x.device.type, enabled=False):
+            x = self.inverse_transform(x)
+        return x.to(dtype), residual

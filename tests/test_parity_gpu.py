@@ -171,3 +171,58 @@ def test_sfno_full_config_backward_vs_oracle(dev):
     errs = {n: rel(pn[n].grad, po[n].grad, floor=1e-1 * scale) for n in sample}
     worst = max(errs, key=errs.get)
     assert errs[worst] < 5 * TOL, (worst, errs[worst])
+
+
+@pytest.mark.parametrize("operator_type,activation,bias", [("diagonal", "real", False), ("l-dependant", "cartesian", True),
+                                                            ("diagonal", "modulus", True)])
+def test_spectral_attention_filter(dev, operator_type, activation, bias):
+    """The non-linear filter: HIP transforms around a complex channel MLP, against the same arithmetic on the oracle's CPU
+    transforms (forward value and input gradient).  Parity of the class itself is unpinned: the reference's forward_mlp
+    cannot run (see the class docstring)."""
+    from makani_amd.sht import InverseRealSHT, RealSHT
+    from makani_amd.spectral_convolution import SpectralAttention
+    from oracle import spectral as osp
+    torch.manual_seed(17)
+    nlat, nlon, C = 33, 64, 6
+    kw = dict(lmax=20, mmax=21, grid="equiangular")
+    mod = SpectralAttention(RealSHT(nlat, nlon, **kw), InverseRealSHT(nlat, nlon, **kw), C, C, operator_type=operator_type,
+                            hidden_size_factor=2, complex_activation=activation, bias=bias, spectral_layers=2).to(dev)
+    x = torch.randn(2, C, nlat, nlon)
+    xd = x.to(dev).requires_grad_(True)
+    y, res = mod(xd)
+    assert res is xd and y.shape == x.shape
+    g = torch.randn_like(x)
+    y.backward(g.to(dev))
+    sht, isht = osp.TorchRealSHT(nlat, nlon, **kw), osp.TorchInverseRealSHT(nlat, nlon, **kw)
+    xo = x.clone().requires_grad_(True)
+    c = sht(xo)
+    eq = "bixy,io->boxy" if operator_type == "diagonal" else "bixy,xio->boxy"
+    for layer in range(2):
+        c = torch.einsum(eq, c, mod.w[layer].detach().cpu())
+        if bias:
+            c = c + mod.b[layer].detach().cpu()
+        act = mod.activations[layer]
+        if activation == "real":
+            c = torch.complex(torch.relu(c.real), c.imag)
+        elif activation == "cartesian":
+            c = torch.complex(torch.relu(c.real), torch.relu(c.imag))
+        else:
+            mag = c.abs()
+            b0 = act.bias.detach().cpu()
+            c = torch.where(mag + b0 > 0, (mag + b0) * c / mag, torch.zeros_like(c))
+    yo = isht(torch.einsum(eq, c, mod.wout.detach().cpu()))
+    yo.backward(g)
+    assert rel(y, yo) < 1e-5
+    assert rel(xd.grad, xo.grad) < 5e-5
+
+
+def test_sfno_with_non_linear_filter_steps(dev):
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    torch.manual_seed(2)
+    kw = dict(inp_shape=(33, 64), out_shape=(33, 64), scale_factor=2, inp_chans=3, out_chans=2, embed_dim=8, num_layers=2)
+    net = SphericalFourierNeuralOperatorNet(filter_type="non-linear", operator_type="diagonal", **kw).to(dev)
+    y = net(torch.randn(2, 3, 33, 64, device=dev))
+    y.square().mean().backward()
+    assert y.shape == (2, 2, 33, 64) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+    with pytest.raises(ValueError):          # the network default operator_type="dhconv" is not one of the attention's
+        SphericalFourierNeuralOperatorNet(filter_type="non-linear", **kw)
