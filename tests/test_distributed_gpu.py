@@ -203,6 +203,57 @@ def _body_pipeline(dev):
         assert _rel(got, want, floor=0.1 * scale) < 1e-4, n
 
 
+def _body_net_bf16(dev):
+    """h = 2 under bf16 autocast: the pointwise stack runs on the pixel-column engine, the block tail on the fused
+    conv + norm node (local row sums -> all-reduce over the spatial group -> coefficients -> epilogue).  Against the fp32
+    serial oracle at bf16 accuracy; the fused tail against the unfused one (MK_NORM_SKIP_FUSION=0) at rounding level."""
+    from makani_amd import comm, mappings
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from makani_amd.distributed import compute_split_shapes
+    from oracle import spectral as osp
+    torch.manual_seed(77)
+    kw = dict(inp_shape=(64, 128), out_shape=(64, 128), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=16, num_layers=2)
+    ref = osp.SphericalFourierNeuralOperatorNet(**kw)
+    net = SphericalFourierNeuralOperatorNet(**kw)
+    hs, hr = comm.get_size("h"), comm.get_rank("h")
+    sd = ref.state_dict()
+    for k in list(sd):
+        if k.endswith("filter.filter.weight"):
+            sd[k] = torch.split(sd[k], compute_split_shapes(sd[k].shape[-1], hs), dim=-1)[hr].contiguous()
+    net.load_state_dict(sd, strict=True)
+    net = net.to(dev)
+    xg, tg = torch.randn(2, 4, 64, 128), torch.randn(2, 3, 64, 128)
+    yo = ref(xg)
+    ((yo - tg) ** 2).sum().backward()
+    xl, tl = _shard(xg, 2, "h").to(dev), _shard(tg, 2, "h").to(dev)
+
+    def step():
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(xl)
+        ((y.float() - tl) ** 2).sum().backward()
+        mappings.reduce_shared_gradients(net)
+        return y.detach().float(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+    y1, g1 = step()
+    assert _rel(_gather(y1, 2, "h"), yo.detach()) < 3e-2
+    po = dict(ref.named_parameters())
+    scale = float(np.median([p.grad.norm().item() for p in po.values()]))
+    for n, g in g1.items():
+        want = po[n].grad
+        if n.endswith("filter.filter.weight"):
+            want = torch.split(want, compute_split_shapes(want.shape[-1], hs), dim=-1)[hr]
+        assert _rel(g, want, floor=0.1 * scale) < 8e-2, n
+    os.environ["MK_NORM_SKIP_FUSION"] = "0"
+    try:
+        y0, g0 = step()
+    finally:
+        del os.environ["MK_NORM_SKIP_FUSION"]
+    assert _rel(y1, y0) < 1e-2
+    for n in g1:
+        assert _rel(g1[n], g0[n], floor=0.1 * scale) < 2e-2, n
+
+
 def _body_sht_w(dev):
     """Longitude sharding (w = 2): the azimuth transposes around the FFT with the real kernels."""
     from makani_amd.distributed import DistributedRealSHT, DistributedInverseRealSHT
@@ -245,7 +296,7 @@ def _worker(rank, world, port, what, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("what", ["sht", "sht_w", "norm", "net", "pipeline"])
+@pytest.mark.parametrize("what", ["sht", "sht_w", "norm", "net", "net_bf16", "pipeline"])
 def test_h2_on_one_gpu(what):
     assert torch.cuda.device_count() >= 1
     ctx = mp.get_context("spawn")
