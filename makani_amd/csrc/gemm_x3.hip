@@ -21,6 +21,11 @@
 // bytes by a third (fp32 tiles, MK_X3_TABLE=f32) moves the total by 2 %, and a half-step pipeline (refill k 0..15 of
 // the stage while the MFMAs read k 16..31, barriers that wait on nothing) left Legendre unchanged and cost dhconv
 // 5-10 %: neither bytes nor the barrier placement is the limit.
+// (Found in round 2: the stagers' gload used to finish with `valid ? loaded : 0` selects -- a use of the loaded value, so the
+// compiler waited out the whole load latency right after issuing the loads, BEFORE the MFMAs of the current k-step, in all
+// five kernels.  The masks now travel to sstore; the loads fly under the matrix work: dhconv forward 0.308 -> 0.269 ms.
+// Tried on top: a ring two k-steps deep (MK_X3_DB=2: Legendre 0.29 -> 0.42 ms) and producer / consumer workgroups -- four
+// staging waves, four multiplying waves, two LDS stages, one barrier per k-step, one workgroup per CU: 0.317 ms.)
 //
 // Operands whose contraction index is the slow memory axis (k-major rows, n contiguous) are transposed
 // in the staging pass: a thread loads 8 consecutive k of two adjacent columns (float2 per row, 512 B per
@@ -39,6 +44,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP uint4 arrays end up in scratch
 
+#ifndef MK_X3_DB
+#define MK_X3_DB 1
+#endif
+constexpr int X3_DB = MK_X3_DB;               // register-ring depth of the streamed (B) operand, in k-steps
 constexpr int XT = 256;                       // threads
 constexpr int XM = 128, XN = 128, XK = 32;    // workgroup tile, k-step
 constexpr int XPITCH = 208;                   // LDS row pitch: 192 data + 16 pad (13 x 16 B: odd)
@@ -149,20 +158,26 @@ struct TransStager {
     const float* base;
     long long ldk;
     int k_lo, k_hi, cvalid;
-    typedef float2 Regs[8];
+    // gload only ISSUES the loads: nothing in it may consume a loaded value, or the compiler has to wait for the whole
+    // latency right there, before the MFMAs of the current k-step (the `ok ? v : 0` select that used to sit here did
+    // exactly that in every kernel of this file).  The validity of the 8 k rows travels as a bit mask to sstore.
+    struct Regs {
+        float2 v[8];
+        unsigned ok;
+    };
     static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
         const int w = tid >> 6, c = (tid & 63) * 2;
         const int k0 = kt * XK + w * 8;
         const float* p = base + (c < cvalid ? c : 0);
+        r.ok = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = k0 + i;
-            const bool ok = k >= k_lo && k < k_hi;
+            if (k >= k_lo && k < k_hi) r.ok |= 1u << i;
             int kc = k < k_lo ? k_lo : k;
             kc = kc < k_hi ? kc : k_hi - 1;   // k_hi >= 1; also covers an empty range (k_lo >= k_hi)
-            const float2 v = *reinterpret_cast<const float2*>(p + (long long)kc * ldk);
-            r[i] = ok ? v : make_float2(0.f, 0.f);
+            r.v[i] = *reinterpret_cast<const float2*>(p + (long long)kc * ldk);
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
@@ -170,8 +185,9 @@ struct TransStager {
         float a[8], b[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            a[i] = r[i].x;
-            b[i] = r[i].y;
+            const bool ok = (r.ok >> i) & 1u;
+            a[i] = ok ? r.v[i].x : 0.f;
+            b[i] = ok ? r.v[i].y : 0.f;
         }
         split_store8(a, img + t * XPITCH + w * 16);
         split_store8(b, img + (t + 64) * XPITCH + 128 + w * 16);
@@ -234,20 +250,21 @@ struct CplxStager {
         const float* p = base + ((long long)kk0 * ldk + (ook ? o : 0)) * 2;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float2 v = make_float2(0.f, 0.f);
-            if (kk0 + i < kk_hi) v = *reinterpret_cast<const float2*>(p + (long long)i * ldk * 2);
-            r[i] = ook ? v : make_float2(0.f, 0.f);
+            r[i] = make_float2(0.f, 0.f);       // (no use of a loaded value in here: see TransStager)
+            if (kk0 + i < kk_hi) r[i] = *reinterpret_cast<const float2*>(p + (long long)i * ldk * 2);
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
         const int w = tid >> 6, t = tid & 63;
+        const bool ook = t < ovalid;            // columns past the end loaded column 0: zero them here
         float a[8], b[8];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            a[2 * i] = r[i].x;
-            a[2 * i + 1] = CONJ_B ? r[i].y : -r[i].y;
-            b[2 * i] = r[i].y;
-            b[2 * i + 1] = CONJ_B ? -r[i].x : r[i].x;
+            const float re = ook ? r[i].x : 0.f, im = ook ? r[i].y : 0.f;
+            a[2 * i] = re;
+            a[2 * i + 1] = CONJ_B ? im : -im;
+            b[2 * i] = im;
+            b[2 * i + 1] = CONJ_B ? -re : re;
         }
         split_store8(a, img + t * XPITCH + w * 16);
         split_store8(b, img + (t + 64) * XPITCH + 128 + w * 16);
@@ -299,9 +316,8 @@ struct WgradAStager {
             const float* p = base + ((long long)r0 * I + (iok ? i : 0)) * 2;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float2 v = make_float2(0.f, 0.f);
-                if (r0 + j < r_hi) v = *reinterpret_cast<const float2*>(p + (long long)j * I * 2);
-                r[4 * e + j] = iok ? v : make_float2(0.f, 0.f);
+                r[4 * e + j] = make_float2(0.f, 0.f);       // (no use of a loaded value in here: see TransStager)
+                if (r0 + j < r_hi) r[4 * e + j] = *reinterpret_cast<const float2*>(p + (long long)j * I * 2);
             }
         }
     }
@@ -309,8 +325,9 @@ struct WgradAStager {
         const int w = tid >> 6, t = tid & 63;
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const float v[8] = {r[4 * e].x, r[4 * e].y, r[4 * e + 1].x, r[4 * e + 1].y,
-                                r[4 * e + 2].x, r[4 * e + 2].y, r[4 * e + 3].x, r[4 * e + 3].y};
+            const float z = (t + 64 * e) < ivalid ? 1.f : 0.f;      // columns past the end loaded column 0: zero them here
+            const float v[8] = {z * r[4 * e].x, z * r[4 * e].y, z * r[4 * e + 1].x, z * r[4 * e + 1].y,
+                                z * r[4 * e + 2].x, z * r[4 * e + 2].y, z * r[4 * e + 3].x, z * r[4 * e + 3].y};
             split_store8(v, img + (t + 64 * e) * XPITCH + w * 16);
         }
     }
@@ -485,7 +502,7 @@ __global__ __launch_bounds__(XT, 3) void legendre_fwd_x3_kernel(LegX3Params p) {
     bs.k_lo = 0;
     bs.k_hi = p.K;
     bs.cvalid = p.N2 - n0;
-    x3_tile<1>(as, bs, 0, p.KC, p.L - l0, p.N2 - n0, p.dst + ((long long)l0 * p.Mloc + m) * p.N2 + n0,
+    x3_tile<X3_DB>(as, bs, 0, p.KC, p.L - l0, p.N2 - n0, p.dst + ((long long)l0 * p.Mloc + m) * p.N2 + n0,
             (long long)p.Mloc * p.N2, lds_x3, p.exp);
 }
 
@@ -509,7 +526,7 @@ __global__ __launch_bounds__(XT, 3) void legendre_inv_x3_kernel(LegX3Params p) {
     bs.cvalid = p.N2 - n0;
     const int kt0 = mg >> 5;
     float* cb = p.kmajor ? p.dst + ((long long)k0 * p.Mloc + m) * p.N2 + n0 : p.dst + ((long long)m * p.K + k0) * p.N2 + n0;
-    x3_tile<1>(as, bs, kt0 < p.KC ? kt0 : p.KC, p.KC, p.K - k0, p.N2 - n0, cb,
+    x3_tile<X3_DB>(as, bs, kt0 < p.KC ? kt0 : p.KC, p.KC, p.K - k0, p.N2 - n0, cb,
                p.kmajor ? (long long)p.Mloc * p.N2 : (long long)p.N2, lds_x3, p.exp);
 }
 
@@ -550,8 +567,8 @@ __global__ __launch_bounds__(XT, 3) void dhconv_fwd_x3_kernel(DhX3Params p) {
     bs.ldk = p.O;
     bs.kk_hi = p.I;
     bs.ovalid = p.O - n0 / 2;
-    x3_tile<1>(as, bs, 0, (2 * p.I + XK - 1) / XK, R - r0, 2 * p.O - n0, p.dst + rowbase * 2 * p.O + n0, 2LL * p.O, lds_x3,
-               p.exp);
+    x3_tile<X3_DB>(as, bs, 0, (2 * p.I + XK - 1) / XK, R - r0, 2 * p.O - n0, p.dst + rowbase * 2 * p.O + n0, 2LL * p.O, lds_x3,
+                   p.exp);
 }
 
 // gx[l][r][:] = gy[l][r][:] * conj(w[l])^T
@@ -574,7 +591,7 @@ __global__ __launch_bounds__(XT, 3) void dhconv_dgrad_x3_kernel(DhX3Params p) {
     bs.base = p.b + ((long long)l * p.I + n0 / 2) * p.O * 2;
     bs.O = p.O;
     bs.ivalid = p.I - n0 / 2;
-    x3_tile<1>(as, bs, 0, (2 * p.O + XK - 1) / XK, R - r0, 2 * p.I - n0, p.dst + rowbase * 2 * p.I + n0, 2LL * p.I, lds_x3,
+    x3_tile<X3_DB>(as, bs, 0, (2 * p.O + XK - 1) / XK, R - r0, 2 * p.I - n0, p.dst + rowbase * 2 * p.I + n0, 2LL * p.I, lds_x3,
                p.exp);
 }
 
@@ -599,7 +616,7 @@ __global__ __launch_bounds__(XT, 3) void dhconv_wgrad_x3_kernel(DhX3Params p) {
     bs.ldk = p.O;
     bs.kk_hi = R;
     bs.ovalid = p.O - n0 / 2;
-    x3_tile<1>(as, bs, 0, (2 * R + XK - 1) / XK, p.I - i0, 2 * p.O - n0, p.dst + ((long long)l * p.I + i0) * 2 * p.O + n0,
+    x3_tile<X3_DB>(as, bs, 0, (2 * R + XK - 1) / XK, p.I - i0, 2 * p.O - n0, p.dst + ((long long)l * p.I + i0) * 2 * p.O + n0,
                2LL * p.O, lds_x3, p.exp);
 }
 
