@@ -129,7 +129,6 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     float2 tw15[15];
 #pragma unroll
     for (int r = 0; r < 15; ++r) tw15[r] = tw[((tid & 15) * r) * S];
-
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
         const int v = tid + it * STHREADS;
@@ -156,6 +155,12 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     }
     __syncthreads();
     if (!(exp & 2)) split_passes(lds, tid, S, tw15);
+    // exp(-2 pi i s' (tid / G) / N), s' = S, 1, 2: the split step's twiddles of this thread's first item -- issued here, where
+    // the pass twiddles are dead (register peak) and the barrier below covers part of the latency
+    float2 wfirst[S];
+    wfirst[0] = tw[HH + S * (tid / G)];
+#pragma unroll
+    for (int s = 1; s < S; ++s) wfirst[s] = tw[HH + s * (tid / G)];
     __syncthreads();
     if (exp & 8) return;
 
@@ -164,44 +169,58 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     //   X[m]     = sum_s W^{s m} F_s[m],   X[240-m] = sum_s conj(W^{s m}) e^{-i pi s/S} F_s[240-m]
     const float2* tw2 = tw + HH;  // exp(-2 pi i m / N)
     constexpr int NPAIR = SH / 2 + 1;  // mp = 0 .. 120
-    for (int idx = tid; idx < G * NPAIR; idx += STHREADS) {
-        const int mp = idx / G, g = idx - mp * G;
-        const int bc = bc0 + g;
-        if (bc >= BC) continue;
-        const int m1 = SH - mp;                 // partner mode (240 for mp = 0)
-        const int p0 = phi(mp), p1 = phi(mp == 0 ? 0 : m1);
-        const float2 wsub = tw2[S * mp];        // exp(-2 pi i mp / 480)
-        float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+    // Thread (mp0, g) = (tid / G, tid % G) handles the mode pairs mp0, mp0 + STEP, ... of channel g (STEP = 384 / G is a
+    // whole number: 16 or 48).  Its twiddles exp(-2 pi i s mp / N) come from ONE exact table read per s (for mp0, issued
+    // with the row loads at the top of the kernel) and one rotation by an exact, thread-uniform table value per item --
+    // the per-item table reads this replaces were dependent global loads in the middle of the loop (latency exposed 8 times
+    // per tile), and the item -> (mp, g) map cost an integer division each.
+    constexpr int STEP = STHREADS / G, PIT = (NPAIR + STEP - 1) / STEP;
+    static_assert(STHREADS % G == 0, "items of a thread must keep their channel");
+    const int mp0 = tid / G, g = tid - mp0 * G;
+    if (bc0 + g < BC) {
+        float2* dst0 = xf + xc.pbase + ((size_t)mp0 * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g);              // mode mp0
+        float2* dst1 = xf + xc.pbase + ((size_t)(SH - mp0) * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g);       // partner
+        const ptrdiff_t dstep = (ptrdiff_t)STEP * xl.sm * xc.BCx;
 #pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const float2* zs = lds + sub_base(g * S + s, S);
-            const float2 a = zs[p0];
-            const float2 b = zs[p1];
-            const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
-            const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
-            const float2 pp = cmul(wsub, d);
-            float2 f0 = make_float2(e.x + pp.y, e.y - pp.x);
-            float2 f1 = make_float2(e.x - pp.y, -e.y - pp.x);
-            if (s > 0) {
-                const float2 w = tw2[s * mp];
-                constexpr float kc[3] = {1.f, 0.5f, -0.5f}, ks[3] = {0.f, -0.86602540378443864676f, -0.86602540378443864676f};
-                static_assert(S == 1 || S == 3, "combine constants are for S = 3");
-                f0 = cmul(f0, w);
-                f1 = cmul(f1, cmul(make_float2(w.x, -w.y), make_float2(kc[s], ks[s])));
+        for (int it = 0; it < PIT; ++it) {
+            const int mp = mp0 + STEP * it;
+            if (mp < NPAIR) {
+                const int m1 = SH - mp;                 // partner mode (240 for mp = 0)
+                const int p0 = phi(mp), p1 = phi(mp == 0 ? 0 : m1);
+                const float2 wsub = it ? cmul(wfirst[0], tw2[S * STEP * it]) : wfirst[0];      // exp(-2 pi i mp / 480)
+                float2 acc0 = make_float2(0.f, 0.f), acc1 = make_float2(0.f, 0.f);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float2* zs = lds + sub_base(g * S + s, S);
+                    const float2 a = zs[p0];
+                    const float2 b = zs[p1];
+                    const float2 e = make_float2(0.5f * (a.x + b.x), 0.5f * (a.y - b.y));
+                    const float2 d = make_float2(0.5f * (a.x - b.x), 0.5f * (a.y + b.y));
+                    const float2 pp = cmul(wsub, d);
+                    float2 f0 = make_float2(e.x + pp.y, e.y - pp.x);
+                    float2 f1 = make_float2(e.x - pp.y, -e.y - pp.x);
+                    if (s > 0) {
+                        const float2 w = it ? cmul(wfirst[s], tw2[s * STEP * it]) : wfirst[s];       // exp(-2 pi i s mp / N)
+                        constexpr float kc[3] = {1.f, 0.5f, -0.5f}, ks[3] = {0.f, -0.86602540378443864676f, -0.86602540378443864676f};
+                        static_assert(S == 1 || S == 3, "combine constants are for S = 3");
+                        f0 = cmul(f0, w);
+                        f1 = cmul(f1, cmul(make_float2(w.x, -w.y), make_float2(kc[s], ks[s])));
+                    }
+                    acc0 = cadd(acc0, f0);
+                    acc1 = cadd(acc1, f1);
+                }
+                if (exp & 4) {   // ablation: keep the arithmetic alive, store (almost) nothing
+                    if (acc0.x + acc1.x != 12345.678f) continue;
+                }
+                if (mp < M) {
+                    const float sc = (mp == 0) ? scale0 : scale_m;
+                    dst0[(ptrdiff_t)it * dstep] = make_float2(sc * acc0.x, sc * acc0.y);
+                }
+                if (m1 != mp && m1 < M) {
+                    const float sc = (m1 == HH) ? scale_h : scale_m;
+                    dst1[-(ptrdiff_t)it * dstep] = make_float2(sc * acc1.x, sc * acc1.y);
+                }
             }
-            acc0 = cadd(acc0, f0);
-            acc1 = cadd(acc1, f1);
-        }
-        if (exp & 4) {   // ablation: keep the arithmetic alive, store (almost) nothing
-            if (acc0.x + acc1.x != 12345.678f) continue;
-        }
-        if (mp < M) {
-            const float sc = (mp == 0) ? scale0 : scale_m;
-            xf[xc.pbase + ((size_t)mp * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)] = make_float2(sc * acc0.x, sc * acc0.y);
-        }
-        if (m1 != mp && m1 < M) {
-            const float sc = (m1 == HH) ? scale_h : scale_m;
-            xf[xc.pbase + ((size_t)m1 * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)] = make_float2(sc * acc1.x, sc * acc1.y);
         }
     }
 }
@@ -247,50 +266,63 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
 #pragma unroll
     for (int r = 0; r < 15; ++r) tw15[r] = tw[((tid & 15) * r) * S];
 
+    float2 wfirst[S];        // exp(-2 pi i s' (tid / G) / N), s' = S, 1, 2: merge-step twiddles of this thread's first item
+    wfirst[0] = tw2[S * (tid / G)];
+#pragma unroll
+    for (int s = 1; s < S; ++s) wfirst[s] = tw2[s * (tid / G)];
+
     // merge step, modes j and 240 - j together (both need X[j] and X[240 - j]):
     //   Y_s[m] = X[m] W^{-s m};  e = Ya + conj Yb, t = w_j (Ya - conj Yb), w_j = exp(+2 pi i j / 480)
     //   Z[j] = e + i t,  Z[240-j] = conj(e) + i conj(t); stored conjugated (inverse = conj . forward . conj)
     constexpr int NPAIR = SH / 2 + 1;
     constexpr int PIT = (G * NPAIR + STHREADS - 1) / STHREADS;
     float2 xa[PIT], xb[PIT];
+    // Thread (jp0, g) = (tid / G, tid % G) owns the mode pairs jp0, jp0 + STEP, ... of channel g (STEP = 384 / G: 16 or 48),
+    // in the gathers and in the merge step alike.
+    constexpr int STEP = STHREADS / G;
+    static_assert(STHREADS % G == 0 && PIT == (NPAIR + STEP - 1) / STEP, "items of a thread keep their channel");
     auto gather = [&](int t, int tl) {      // the 8-byte mode gathers of tile t (in flight while the previous tile computes)
         const int k = t / ntile, bc0 = (t - k * ntile) * G;
         const XfChan xc = xf_chan(xl, bc0, BC);
+        const int jp0 = tl / G, g = tl - jp0 * G;
+        const bool chan_ok = bc0 + g < BC;
+        // Every load is issued unconditionally (element 0 of xf where there is nothing to fetch) and nothing here consumes a
+        // loaded value: a conditional load into a pre-zeroed register became load + copy, and the copy made the compiler wait
+        // for the whole gather right here instead of after the FFT passes of the current tile.  The merge step masks.
+        const float2* base = xf + xc.pbase + (size_t)k * xl.sk * xc.BCx + (xc.bcx0 + g);
 #pragma unroll
         for (int it = 0; it < PIT; ++it) {
-            const int idx = tl + it * STHREADS;
-            const int jp = idx / G, g = idx - jp * G;
-            const int bc = bc0 + g, j1 = SH - jp;
-            xa[it] = make_float2(0.f, 0.f);
-            xb[it] = make_float2(0.f, 0.f);
-            if (idx < G * NPAIR && bc < BC) {
-                if (jp < M) xa[it] = xf[xc.pbase + ((size_t)jp * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)];
-                if (j1 < M) xb[it] = xf[xc.pbase + ((size_t)j1 * xl.sm + (size_t)k * xl.sk) * xc.BCx + (xc.bcx0 + g)];
-            }
+            const int jp = jp0 + STEP * it, j1 = SH - jp;
+            const bool oa = chan_ok && jp < NPAIR && jp < M, ob = chan_ok && jp < NPAIR && j1 < M;
+            xa[it] = *(oa ? base + (size_t)jp * xl.sm * xc.BCx : xf);
+            xb[it] = *(ob ? base + (size_t)j1 * xl.sm * xc.BCx : xf);
         }
     };
     gather(tile, tid);
   for (;;) {
     const int tl = opaque(tid);
     const int k = tile / ntile, bc0 = (tile - k * ntile) * G;
+    const int jp0 = tl / G, g = tl - jp0 * G;
+    const bool chan_ok = bc0 + g < BC;
 #pragma unroll
     for (int it = 0; it < PIT; ++it) {
-        const int idx = tl + it * STHREADS;
-        if (idx >= G * NPAIR) continue;
-        const int jp = idx / G, g = idx - jp * G;
+        const int jp = jp0 + STEP * it;
+        if (jp >= NPAIR) continue;
         const int j1 = SH - jp;
-        const float sa = (jp == 0) ? scale0 : scale_m;
-        const float sb = (j1 == HH) ? scale_h : scale_m;
+        const float sa = (chan_ok && jp < M) ? ((jp == 0) ? scale0 : scale_m) : 0.f;      // the gather's masks (see there)
+        const float sb = (chan_ok && j1 < M) ? ((j1 == HH) ? scale_h : scale_m) : 0.f;
         const float2 a0 = make_float2(sa * xa[it].x, sa * xa[it].y);
         const float2 b0 = make_float2(sb * xb[it].x, sb * xb[it].y);
-        float2 wsub = tw2[S * jp];
+        // twiddles: one exact table value per thread (its first item, loaded once per launch) rotated by an exact,
+        // thread-uniform table value per item -- no dependent table reads inside the loop
+        float2 wsub = it ? cmul(wfirst[0], tw2[S * STEP * it]) : wfirst[0];
         wsub.y = -wsub.y;  // exp(+2 pi i jp / 480)
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             float2 ya = a0, yb = b0;
             if (s > 0) {
                 constexpr float kc[3] = {1.f, 0.5f, -0.5f}, ks[3] = {0.f, 0.86602540378443864676f, 0.86602540378443864676f};
-                const float2 w = tw2[s * jp];                  // W^{s jp}
+                const float2 w = it ? cmul(wfirst[s], tw2[s * STEP * it]) : wfirst[s];      // W^{s jp}
                 ya = cmul(ya, make_float2(w.x, -w.y));          // X[j]  W^{-s j}
                 yb = cmul(yb, cmul(w, make_float2(kc[s], ks[s])));  // X[j1] W^{-s (240 - j)} = X[j1] e^{+i pi s/3} W^{s j}
             }
