@@ -91,6 +91,24 @@ __device__ __forceinline__ void split_store8(const float (&v)[8], char* dst) {
     *reinterpret_cast<uint4*>(dst + 128) = l;
 }
 
+// Branch-free masked loads: a raw buffer load whose lane offset lies past the descriptor's range returns zeros, so an
+// invalid lane simply gets the offset X3_OOB -- no exec-mask branch around the load, no `valid ? loaded : 0` select after it
+// (a use of the loaded value: the compiler then waits out the load latency on the spot, before the MFMAs of the k-step) and
+// no copy out of a conditionally loaded register (same effect).  The loads of a k-step are issued back to back and are
+// waited for where the LDS-staging step reads them.  Offsets are bytes from the stager's base pointer (< 2^31).
+typedef unsigned int x3_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int x3_u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned X3_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x3_rsrc(const float* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4 x3_load16(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
+}
+__device__ __forceinline__ float2 x3_load8(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rs, off, 0, 0));
+}
+
 // ---------------------------------------------------------------------------
 // Stagers: Regs, gload(kt, regs, tid), sstore(regs, image, tid), row_off(r)
 // ---------------------------------------------------------------------------
@@ -158,26 +176,17 @@ struct TransStager {
     const float* base;
     long long ldk;
     int k_lo, k_hi, cvalid;
-    // gload only ISSUES the loads: nothing in it may consume a loaded value, or the compiler has to wait for the whole
-    // latency right there, before the MFMAs of the current k-step (the `ok ? v : 0` select that used to sit here did
-    // exactly that in every kernel of this file).  The validity of the 8 k rows travels as a bit mask to sstore.
-    struct Regs {
-        float2 v[8];
-        unsigned ok;
-    };
+    typedef float2 Regs[8];
     static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
         const int w = tid >> 6, c = (tid & 63) * 2;
         const int k0 = kt * XK + w * 8;
-        const float* p = base + (c < cvalid ? c : 0);
-        r.ok = 0;
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = k0 + i;
-            if (k >= k_lo && k < k_hi) r.ok |= 1u << i;
-            int kc = k < k_lo ? k_lo : k;
-            kc = kc < k_hi ? kc : k_hi - 1;   // k_hi >= 1; also covers an empty range (k_lo >= k_hi)
-            r.v[i] = *reinterpret_cast<const float2*>(p + (long long)kc * ldk);
+            const bool ok = k >= k_lo && k < k_hi && c < cvalid;
+            r[i] = x3_load8(rs, ok ? (unsigned)(((long long)k * ldk + c) * 4) : X3_OOB);
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
@@ -185,9 +194,8 @@ struct TransStager {
         float a[8], b[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const bool ok = (r.ok >> i) & 1u;
-            a[i] = ok ? r.v[i].x : 0.f;
-            b[i] = ok ? r.v[i].y : 0.f;
+            a[i] = r[i].x;
+            b[i] = r[i].y;
         }
         split_store8(a, img + t * XPITCH + w * 16);
         split_store8(b, img + (t + 64) * XPITCH + 128 + w * 16);
@@ -210,15 +218,14 @@ struct RowStager {
     typedef float4 Regs[4];
     static __device__ __forceinline__ int row_off(int r) { return plain_off(r); }
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base);
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int t = tid + q * XT, row = (t >> 6) * 16 + quad_row(t & 63), k = kt * XK + (t & 3) * 8;
-            const float* p = base + (long long)row * ld + k;
+            const unsigned off = (unsigned)(((long long)row * ld + k) * 4);
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                r[2 * q + h] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (row < rows && k + 4 * h < kvalid) r[2 * q + h] = *reinterpret_cast<const float4*>(p + 4 * h);
-            }
+            for (int h = 0; h < 2; ++h)
+                r[2 * q + h] = x3_load16(rs, (row < rows && k + 4 * h < kvalid) ? off + 16 * h : X3_OOB);
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
@@ -247,12 +254,10 @@ struct CplxStager {
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), o = tid & 63;
         const int kk0 = kt * (XK / 2) + w * 4;
         const bool ook = o < ovalid;
-        const float* p = base + ((long long)kk0 * ldk + (ook ? o : 0)) * 2;
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            r[i] = make_float2(0.f, 0.f);       // (no use of a loaded value in here: see TransStager)
-            if (kk0 + i < kk_hi) r[i] = *reinterpret_cast<const float2*>(p + (long long)i * ldk * 2);
-        }
+        for (int i = 0; i < 4; ++i)
+            r[i] = x3_load8(rs, (ook && kk0 + i < kk_hi) ? (unsigned)((((long long)(kk0 + i)) * ldk + o) * 8) : X3_OOB);
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
         const int w = tid >> 6, t = tid & 63;
@@ -281,12 +286,10 @@ struct DgradStager {
     static __device__ __forceinline__ int row_off(int r) { return pair_off(r); }
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
         const int i = (tid >> 6) * 16 + quad_row(tid & 63), o = kt * (XK / 2) + (tid & 3) * 4;
-        const float* p = base + ((long long)i * O + o) * 2;
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base);
+        const unsigned off = (unsigned)(((long long)i * O + o) * 8);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            r[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (i < ivalid && o + 2 * h < O) r[h] = *reinterpret_cast<const float4*>(p + 4 * h);
-        }
+        for (int h = 0; h < 2; ++h) r[h] = x3_load16(rs, (i < ivalid && o + 2 * h < O) ? off + 16 * h : X3_OOB);
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
         const int i = (tid >> 6) * 16 + quad_row(tid & 63), c = tid & 3;
@@ -309,16 +312,14 @@ struct WgradAStager {
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
         const int w = __builtin_amdgcn_readfirstlane(tid >> 6), t = tid & 63;
         const int r0 = kt * (XK / 2) + w * 4;
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base);
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int i = t + 64 * e;
             const bool iok = i < ivalid;
-            const float* p = base + ((long long)r0 * I + (iok ? i : 0)) * 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                r[4 * e + j] = make_float2(0.f, 0.f);       // (no use of a loaded value in here: see TransStager)
-                if (r0 + j < r_hi) r[4 * e + j] = *reinterpret_cast<const float2*>(p + (long long)j * I * 2);
-            }
+            for (int j = 0; j < 4; ++j)
+                r[4 * e + j] = x3_load8(rs, (iok && r0 + j < r_hi) ? (unsigned)((((long long)(r0 + j)) * I + i) * 8) : X3_OOB);
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
