@@ -40,16 +40,23 @@ struct WgradParams {
 
 // (NV * 256 / WVPR) rows x TK k bf16 tile: NV 16-byte vectors per thread, WVPR = TK / 8 vectors per row,
 // LDS row pitch WPITCH = 2 TK + 16 bytes (an odd number of 16-byte units: conflict-free ds_read_b128)
+// Loads are raw buffer loads: a lane outside the tile (row past the operand, pixel past the slab) gets an offset past the
+// descriptor's range and reads zeros -- no exec-mask branch per vector, nothing that makes the compiler wait for a load
+// where it is issued (same finding as in gemm_x3.hip).  Offsets are bytes from the block's first row (< 2^31: at most
+// 256 rows of 2 P bytes).
 template <int NV, int WVPR>
 __device__ __forceinline__ void wg_load(const __hip_bfloat16* base, long long ld, int rows_valid, long long k0,
                                         long long kend, uint4 (&r)[NV], int tid) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__hip_bfloat16*>(base), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * WT;
         const int row = v / WVPR, c = v % WVPR;
         const long long k = k0 + c * 8;
-        r[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (row < rows_valid && k < kend) r[i] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
+        const unsigned off = (row < rows_valid && k < kend) ? (unsigned)(((long long)row * ld + k) * 2) : 0x80000000u;
+        r[i] = __builtin_bit_cast(uint4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
 }
 template <int NV, int WVPR>
@@ -175,12 +182,15 @@ constexpr int WT8 = 512;
 template <int NV>
 __device__ __forceinline__ void wg8_load(const __hip_bfloat16* base, long long ld, int rows_valid, long long k0,
                                          long long kend, uint4 (&r)[NV], int tid) {
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<__hip_bfloat16*>(base), 0, 0x7FFFFFFF, 0x00020000);     // see wg_load
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int v = tid + i * WT8, row = v >> 3, c = v & 7;
         const long long k = k0 + c * 8;
-        r[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (row < rows_valid && k < kend) r[i] = *reinterpret_cast<const uint4*>(base + (long long)row * ld + k);
+        const unsigned off = (row < rows_valid && k < kend) ? (unsigned)(((long long)row * ld + k) * 2) : 0x80000000u;
+        r[i] = __builtin_bit_cast(uint4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
     }
 }
 template <int NV>
