@@ -110,19 +110,24 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
     const int bc0 = (tile - k * ntile) * G;
     const XfChan xc = xf_chan(xl, bc0, BC);
 
-    float vals[IT][S][E];
+    // The row loads only ISSUE here -- raw 16-byte buffer loads (a lane with nothing to fetch gets an offset past the
+    // descriptor's range and reads zeros), unpacked to floats where they are staged into LDS.  The earlier form converted
+    // each vector right after its conditional load: a use of the loaded value, so the compiler put `s_waitcnt vmcnt(0)`
+    // behind every one of the 4-6 row loads of a thread and the HBM latency was paid 4-6 times per tile, in series.
+    typedef unsigned int rf_u4 __attribute__((ext_vector_type(4)));
+    uint4 raw[IT][S];
+    {
+        const TIn* tile_base = x + ((size_t)bc0 * K + k) * N;         // offsets below stay < 24 rows x K x N elements
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<TIn*>(tile_base), 0, 0x7FFFFFFF, 0x00020000);
 #pragma unroll
-    for (int it = 0; it < IT; ++it) {
-        const int v = tid + it * STHREADS;
-        const int g = v / GPR, p = v - g * GPR;
-        const bool ok = (v < NGRP) && (bc0 + g < BC) && !(exp & 1);
+        for (int it = 0; it < IT; ++it) {
+            const int v = tid + it * STHREADS;
+            const int g = v / GPR, p = v - g * GPR;
+            const bool ok = (v < NGRP) && (bc0 + g < BC) && !(exp & 1);
 #pragma unroll
-        for (int c = 0; c < S; ++c) {
-            if (ok) {
-                InVec<TIn>::load(x + ((size_t)(bc0 + g) * K + k) * N + (p * S + c) * E, vals[it][c]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < E; ++e) vals[it][c][e] = 0.f;
+            for (int c = 0; c < S; ++c) {
+                const unsigned off = ok ? (unsigned)((((size_t)g * K) * N + (size_t)(p * S + c) * E) * sizeof(TIn)) : 0x80000000u;
+                raw[it][c] = __builtin_bit_cast(uint4, (rf_u4)__builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 0));
             }
         }
     }
@@ -134,6 +139,9 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
         const int v = tid + it * STHREADS;
         if (v < NGRP) {
             const int g = v / GPR, p = v - g * GPR;
+            float vals[S][E];
+#pragma unroll
+            for (int c = 0; c < S; ++c) InVec<TIn>::unpack(raw[it][c], vals[c]);
             // flat element f = c*E + e of the group is real index S*E*p + f = S*n + s: s = f % S, n = E*p + f / S
 #pragma unroll
             for (int sq = 0; sq < S; ++sq) {
@@ -145,7 +153,7 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
                     for (int a = 0; a < 4; ++a) {
                         constexpr int dummy = 0;
                         const int f = (4 * h + a) * S + sq;   // n - E*p = 4h + a
-                        o[a] = vals[it][f / E][f % E];
+                        o[a] = vals[f / E][f % E];
                         (void)dummy;
                     }
                     dst[h] = make_float4(o[0], o[1], o[2], o[3]);
