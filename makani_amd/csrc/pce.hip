@@ -51,6 +51,7 @@ struct PceParams {
     __hip_bfloat16* y;             // [B][M][P]
     const float* bias;             // [nbias] floats, read at min(row, nbias - 1)
     int nbias;
+    unsigned bias_lds;             // streaming kernel: LDS byte address of the workgroup's copy of the bias (set by the kernel)
     const __hip_bfloat16* addend;  // [B][M][P] or null: y += addend
     const float* aff;              // [B][M][2] or null: the addend enters as aff[..][0] * addend + aff[..][1] (a per-row affine map:
                                    // the instance norm of the addend, applied here instead of in a pass of its own)
@@ -255,9 +256,11 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
     };
     // all bias values up front: a load issued between the stores of two tiles would be waited for with vmcnt(0), i.e. behind
     // the round trip of every store queued before it
+    // (the values come from the workgroup's LDS copy: a global load here would expose an L2 round trip per tile)
     float bias_t[TH];
 #pragma unroll
-    for (int t = 0; t < TH; ++t) bias_t[t] = p.bias[min(m_first + 32 * t + m_local, p.nbias - 1)];   // always there (zeros if the layer has none); rows past M are never stored
+    for (int t = 0; t < TH; ++t) bias_t[t] = lds_read_b32(p.bias_lds + 4 * (m_first + 32 * t + m_local));   // zeros if the layer has none
+    wait_lgkm<0>();
     // the addend's per-row affine map (identity without one), loaded with the bias for the same reason
     float aff_a[TH], aff_b[TH];
 #pragma unroll
@@ -455,6 +458,10 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     };
     const uint32_t a_lane = lds_addr(WB) + mh * TH * 1024 + lane * 16;   // this wave's weight fragments inside a ring buffer
     bf16x8 af0[TH], af1[TH];
+    // the bias of all passes, once per workgroup, behind the staging tiles (read by the epilogue of every tile)
+    p.bias_lds = lds_addr(WB) + NBUF * GROUP + 8 * 2048;
+    for (int i = tid; i < p.npass * 64 * TH; i += PT) lds_write_b32(p.bias_lds + 4 * i, p.bias[min(i, p.nbias - 1)]);
+    wait_lgkm<0>();
     if (tile < ntiles) {
         const bool after = p.npass > 1 || tile + (int)gridDim.x < ntiles;
         issue_next_group(after);
@@ -1109,7 +1116,7 @@ static int pce_cu_count() {
 
 template <int KSP, int NPH, int TH, bool HAS_IN>
 static int pce_launch(const PceParams& p, hipStream_t st) {
-    constexpr int LDS = (NPH > 1 ? 2 : 1) * 16 * KSP * XROW + 3 * 2 * 2 * TH * 1024 + 8 * 2048;   // X regions + three weight groups + 8 staging tiles
+    constexpr int LDS = (NPH > 1 ? 2 : 1) * 16 * KSP * XROW + 3 * 2 * 2 * TH * 1024 + 8 * 2048 + 4 * 64 * TH * 4;   // X regions + three weight groups + 8 staging tiles + the bias of up to four passes
     static const bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pce_kernel<KSP, NPH, TH, HAS_IN>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
@@ -1174,6 +1181,7 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
     MK_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wimg & 15) == 0, "x and the weight image must be 16-byte aligned");
     PceCfg c;
     MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768; M <= 384 when K > 384)");
+    MK_REQUIRE(c.npass <= 4, "M <= 1536 (four passes of 384 rows)");
     static const int pexp = [] { const char* e = getenv("MK_PCE_EXP"); return e ? atoi(e) : 0; }();
     MK_REQUIRE(!(addend && aux_in), "addend and aux_in are exclusive");
     MK_REQUIRE(!addend_affine || addend, "addend_affine needs an addend");
