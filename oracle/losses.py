@@ -45,3 +45,27 @@ def geometric_lp_loss(prd, tar, chw, q, p=2, absolute=False, squared=False, size
         norms = frac if squared else frac ** (1.0 / p)           # losses.py:245-246
     out = np.asarray(chw, np.float64) * norms                    # losses.py:223 / 249
     return out.mean() if size_average else out.sum()             # losses.py:225-229
+
+
+def geometric_h1_loss(coeffs_diff, coeffs_tar=None, mask=None, alpha=0.5, squared=False, size_average=False):
+    """losses.py:306-362 on given spherical-harmonic coefficients [B, C, L, M] (complex) of the error (and of the target for
+    the relative form): norm2[l] = |c[l,0]|^2 + 2 sum_{m>0} |c[l,m]|^2, L2 = sum_l norm2, H1 = sum_l l (l + 1) norm2."""
+    def norms(c):
+        c = np.asarray(c)
+        a = np.abs(c) ** 2
+        norm2 = a[..., 0] + 2.0 * a[..., 1:].sum(axis=-1)                     # losses.py:310-311
+        l = np.arange(c.shape[-2], dtype=np.float64)
+        n = c.shape[0]
+        return norm2.reshape(n, -1).sum(axis=-1), (norm2 * (l * (l + 1))).reshape(n, -1).sum(axis=-1)   # 312-313
+
+    def combine(l2, h1):
+        return alpha * l2 + (1 - alpha) * h1 if squared else alpha * np.sqrt(l2) + (1 - alpha) * np.sqrt(h1)   # 315-318
+
+    out = combine(*norms(coeffs_diff))
+    if coeffs_tar is not None:
+        out = out / combine(*norms(coeffs_tar))                                # 348
+        if mask is not None:
+            out = out * np.asarray(mask, np.float64)                           # 349-350
+            if size_average:
+                return out.sum() / np.asarray(mask, np.float64).sum()          # 356-357
+    return out.mean() if size_average else out.sum()

@@ -226,3 +226,23 @@ def test_sfno_with_non_linear_filter_steps(dev):
     assert y.shape == (2, 2, 33, 64) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
     with pytest.raises(ValueError):          # the network default operator_type="dhconv" is not one of the attention's
         SphericalFourierNeuralOperatorNet(filter_type="non-linear", **kw)
+
+
+@pytest.mark.parametrize("absolute,squared", [(True, False), (True, True), (False, False)])
+def test_geometric_h1_loss(dev, absolute, squared):
+    """losses.py:275-370 on the HIP transform against the oracle's formula applied to the oracle's CPU coefficients."""
+    from makani_amd.losses import GeometricH1Loss
+    from oracle import losses as ol
+    from oracle import spectral as osp
+    torch.manual_seed(6)
+    B, C, H, W = 2, 3, 33, 64
+    prd, tar = torch.randn(B, C, H, W), torch.randn(B, C, H, W)
+    loss = GeometricH1Loss((H, W), absolute=absolute, squared=squared).to(dev)
+    pd = prd.to(dev).requires_grad_(True)
+    out = loss(pd, tar.to(dev))
+    out.backward()
+    sht = osp.TorchRealSHT(H, W, grid="equiangular")
+    po = prd.clone().double().requires_grad_(True)
+    want = ol.geometric_h1_loss(sht(prd - tar).numpy(), None if absolute else sht(tar).numpy(), squared=squared)
+    assert abs(float(out.detach()) - want) < 2e-5 * abs(want)
+    assert torch.isfinite(pd.grad).all() and pd.grad.abs().sum() > 0
