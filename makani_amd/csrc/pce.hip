@@ -559,20 +559,23 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             stamp();   // 1
             bf16x8 xf[KSP];
             {
+                // (inline asm, not the builtin: with LDS-DMA in flight the compiler puts s_waitcnt vmcnt(0) in front of every
+                // LDS read it can see -- here that drained the weight groups and the X pieces of the coming phases, HBM
+                // latency included, at the start of every phase: 1,400 cycles in the stamps, three times per tile)
                 const int l = opaque_lane();
                 const int rowq = (l & 15) >> 2;
                 const int ch = 4 * pg + 2 * ((l >> 4) & 1) + ((l & 3) >> 1);
-                const char* xfrag_lane = XS + region * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
-                                         ((ch + 4 * rowq) & 15) * 16 + (l & 1) * 8;
-                if (!(p.exp & 16))
+                const uint32_t xfrag_lane = lds_addr(XS) + region * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
+                                            ((ch + 4 * rowq) & 15) * 16 + (l & 1) * 8;
+                if (!(p.exp & 16)) {
+                    u32x2 lo[KSP], hi[KSP];
+                    [&]<int... SS>(std::integer_sequence<int, SS...>) {
+                        ((lo[SS] = lds_read_tr16<SS * 16 * XROW>(xfrag_lane), hi[SS] = lds_read_tr16<SS * 16 * XROW + 4 * XROW>(xfrag_lane)), ...);
+                    }(std::make_integer_sequence<int, KSP>{});
+                    wait_lgkm<0>();
 #pragma unroll
-                for (int s = 0; s < KSP; ++s) {
-                    const char* qp = xfrag_lane + s * 16 * XROW;
-                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(qp));
-                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                        (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(qp + 4 * XROW));
-                    xf[s] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+                    for (int s2 = 0; s2 < KSP; ++s2)
+                        xf[s2] = __builtin_bit_cast(bf16x8, u32x4{lo[s2][0], lo[s2][1], hi[s2][0], hi[s2][1]});
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
