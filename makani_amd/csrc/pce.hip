@@ -44,6 +44,12 @@ constexpr int PN = 128;         // pixels per tile
 constexpr int XROW = PN * 2;    // bytes of one k row of the X tile in LDS
 constexpr int PCE_KPHASE = 384; // k rows resident per phase
 
+#ifdef MK_PCE_ABLATE     // profiling build only (tools/pce_ablate.py): run-time ablation checks cost the hot loops
+#define WS_EXP(bit) (p.exp & (bit))
+#else
+#define WS_EXP(bit) false
+#endif
+
 struct PceParams {
     const __hip_bfloat16* x;       // [B][K][P]
     const char* wimg;              // mk_pce_pack image
@@ -448,7 +454,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     // The work of a workgroup is a sequence of ITEMS (tile, pass): all passes of a tile back to back, then the next tile.
     auto issue_next_group = [&](bool item_after_exists) {
         if (si_next && !item_after_exists) return;
-        if (!(p.exp & 4)) issue_group(spass * ngroup_tile + si, gi % NBUF);
+        if (!WS_EXP(4)) issue_group(spass * ngroup_tile + si, gi % NBUF);
         ++gi;
         if (++si == ngroup_tile) {
             si = 0;
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                 const int ch = 4 * pg + 2 * ((l >> 4) & 1) + ((l & 3) >> 1);
                 const uint32_t xfrag_lane = lds_addr(XS) + region * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
                                             ((ch + 4 * rowq) & 15) * 16 + (l & 1) * 8;
-                if (!(p.exp & 16)) {
+                if (!WS_EXP(16)) {
                     u32x2 lo[KSP], hi[KSP];
                     [&]<int... SS>(std::integer_sequence<int, SS...>) {
                         ((lo[SS] = lds_read_tr16<SS * 16 * XROW>(xfrag_lane), hi[SS] = lds_read_tr16<SS * 16 * XROW + 4 * XROW>(xfrag_lane)), ...);
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             // fetched into this region while the phase computes: the phase NREG ahead (of this item, or of the next one)
             XTarget xt;
             xt.active = false;
-            if (!(p.exp & 8)) {
+            if (!WS_EXP(8)) {
                 if (phase + NREG < NPH) xt = x_target(tile, phase + NREG, region);
                 else if (item_after) xt = x_target(next_tile, phase + NREG - NPH, region);
             }
@@ -598,11 +604,11 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                     else if (cx == 1) wait_vm<1>();
                     else wait_vm0();
                 }
-                if (!(p.exp & 32)) block_sync();                // group g + 1 visible; nobody reads group g - 1 any more
+                if (!WS_EXP(32)) block_sync();                  // group g + 1 visible; nobody reads group g - 1 any more
                 stamp();   // 4 + 2 gq
                 issue_next_group(item_after);                   // group g + 2 -> the buffer of group g - 1
                 cx = (gq < XG && xt.active) ? issue_x(xt, gq) : 0;
-                if (!(p.exp & 2)) {
+                if (!WS_EXP(2)) {
                     const uint32_t a = a_lane + (g % NBUF) * GROUP;
                     FragLoop<TH, 0, 0>::issue(a + SLOT, af1);                       // step 1 of group g
                     wait_lgkm<TH>();                                                // af0 (older) has arrived
@@ -633,7 +639,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         landed = gi;
         cx = 0;
         stamp();
-        if (!(p.exp & 1)) {
+        if (!WS_EXP(1)) {
             EpiAddr ea;
             const int l = opaque_lane();
             const uint32_t stg = lds_addr(WB) + NBUF * GROUP + wave * 2048;    // wave-private [32 rows][32 px] bf16 tile
@@ -707,11 +713,7 @@ constexpr int WS_THREADS = 256;
 constexpr int WS_PN = 64;
 constexpr int WS_ROWS = 384;            // rows of one workgroup (4 waves x 3 row tiles)
 constexpr int WS_LDS = 160 * 1024;
-#ifdef MK_PCE_ABLATE     // profiling build only (tools/pce_ablate.py): the run-time checks cost the hot loop ~30 %
-#define WS_EXP(bit) (p.exp & (bit))
-#else
-#define WS_EXP(bit) false
-#endif
+
 
 template <int KSP, int NPH, bool HAS_IN>
 struct WsGeom {
