@@ -320,7 +320,10 @@ def main():
     net = SphericalFourierNeuralOperatorNet(**CONFIG).to(dev)
     mappings.sync_params(net)
     from makani_amd.optim import FusedAdam
-    opt = FusedAdam(net.parameters(), lr=1e-4)
+    # The update of a large tensor starts on a side stream as soon as backward has produced its gradient (optim.py): the
+    # HBM-bound Adam passes of the spectral weights run under the rest of backward.  MK_ADAM_OVERLAP=0: all of it in opt.step().
+    adam_overlap = int(os.environ.get("MK_ADAM_OVERLAP", "1"))
+    opt = FusedAdam(net.parameters(), lr=1e-4, overlap_backward=adam_overlap)
 
     B = world                                   # weak scaling: one sample per GPU
     lat_loc = net.inp_shape_loc[0]
@@ -475,7 +478,9 @@ def main():
                        "global_batch": B, "parallelism": f"h{hsize}", "spectral_dtype": "f32 (GEMMs as 6 bf16 MFMA products of exact 3-way operand splits)"
                        if spectral_mode == "bf16x3" else "f32",
                        "step_launch": "hipGraph replay" if args.graph else "eager",
-                       "micro_batches": nmb, "python_gc": "disabled in the timed region"},
+                       "micro_batches": nmb, "python_gc": "disabled in the timed region",
+                       "adam": ("large tensors updated on a side stream as their gradients arrive, joined in opt.step()"
+                                if (adam_overlap and not args.graph) else "after backward")},
             "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
             "kernel_timing": ("HIP events: all kernels over the last %d warm-up step(s), the roofline kernel over the timed region"
                               % n_probe) if n_probe else ("HIP events over an eager pre-pass" if args.graph else

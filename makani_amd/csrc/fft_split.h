@@ -151,10 +151,8 @@ __global__ __launch_bounds__(STHREADS) void rfft_split_kernel(const TIn* __restr
                     float o[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
-                        constexpr int dummy = 0;
                         const int f = (4 * h + a) * S + sq;   // n - E*p = 4h + a
                         o[a] = vals[f / E][f % E];
-                        (void)dummy;
                     }
                     dst[h] = make_float4(o[0], o[1], o[2], o[3]);
                 }

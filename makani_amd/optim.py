@@ -8,6 +8,15 @@ number as two reals, so every parameter is stepped through a real view of its st
 * large dense tensors (the spectral weights: 283 M of the net's 289 M parameters) by
   ``mk_adam_step`` -- one HIP streaming pass per tensor over its storage in memory order;
 * the many small ones by ``torch.optim.Adam(fused=True)`` in one multi-tensor launch.
+
+``overlap_backward=k`` (opt-in, 0 = off): the update of a large tensor is launched on a side stream as soon as its gradient
+has been accumulated ``k`` times in this step (``k`` = backward passes per step: 1, or the number of micro-batches), so the
+HBM-bound streaming pass runs under the remaining backward kernels (which leave most of the HBM bandwidth idle) instead
+of after them; ``step()`` launches whatever is left and joins the side stream.  The arithmetic and the result are the same
+as without it.  Only valid when nothing is done to these gradients between backward and ``step()``: no gradient clipping
+or scaling, no data-parallel averaging (the spectral weights are sharded, not shared, over the model-parallel groups, so
+``reduce_shared_gradients`` does not touch them).  Under stream capture the hook does nothing (the captured graph ends with
+backward; the optimizer steps outside it, ``trainer.py:762-763``).
 """
 import torch
 
@@ -26,16 +35,23 @@ def _flat_storage_view(t):
 
 
 class FusedAdam:
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, overlap_backward=0):
         self.params = [p for p in params if p.requires_grad]
         self.defaults = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.views, self._small, self._big = [], [], []
+        self.overlap_backward = int(overlap_backward)
+        self._side = None           # side stream of the overlapped updates
+        self._hooks = []
         for p in self.params:
             v = (torch.view_as_real(p.data) if p.is_complex() else p.data).detach()
             self.views.append(v)
             flat = _flat_storage_view(v) if (v.is_cuda and v.dtype == torch.float32 and v.numel() >= _BIG) else None
             if flat is not None and flat.data_ptr() % 16 == 0:
-                self._big.append({"p": p, "flat": flat, "m": torch.zeros_like(flat), "v": torch.zeros_like(flat), "step": 0})
+                st = {"p": p, "flat": flat, "m": torch.zeros_like(flat), "v": torch.zeros_like(flat), "step": 0,
+                      "acc": 0, "done": False}
+                self._big.append(st)
+                if self.overlap_backward > 0:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(lambda _p, st=st: self._grad_ready(st)))
             else:
                 self._small.append((p, v))
         self.opt = None
@@ -48,6 +64,8 @@ class FusedAdam:
         return self.opt.param_groups if self.opt is not None else [dict(self.defaults)]
 
     def zero_grad(self, set_to_none=True):
+        for st in self._big:
+            st["acc"] = 0
         for p, v in zip(self.params, self.views):
             v.grad = None
             if set_to_none:
@@ -64,6 +82,39 @@ class FusedAdam:
             g = g2
         return g
 
+    def _step_big(self, st, stream):
+        """One streaming pass over a large tensor on ``stream`` (a raw HIP stream handle)."""
+        g = self._grad_like_param(st["p"])
+        if g is None:
+            return
+        hp = self.param_groups[0] if self.opt is not None else self.defaults
+        lr, (b1, b2), eps, wd = hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"]
+        gf = _flat_storage_view(torch.view_as_real(g) if g.is_complex() else g)
+        assert gf is not None and gf.dtype == torch.float32 and gf.numel() == st["flat"].numel()
+        st["step"] += 1
+        _lib.check(_lib.load().mk_adam_step(st["flat"].data_ptr(), gf.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(),
+                                            gf.numel(), float(lr), float(b1), float(b2), float(eps), float(wd), st["step"],
+                                            stream), "mk_adam_step")
+
+    def _grad_ready(self, st):
+        """Post-accumulate hook of a large tensor (``overlap_backward``): after the last accumulation of the step its update
+        goes to the side stream, ordered behind everything the accumulating stream has queued so far (the kernels that read
+        the old weights and wrote the gradient)."""
+        st["acc"] += 1
+        if st["acc"] != self.overlap_backward or st["done"] or not st["p"].is_cuda:
+            return
+        if torch.cuda.is_current_stream_capturing():
+            return
+        if self._side is None:
+            import os
+            # lowest priority the device offers: the update should fill what the backward kernels leave idle, not compete
+            prio = int(os.environ.get("MK_ADAM_STREAM_PRIORITY", "1"))
+            self._side = torch.cuda.Stream(device=st["p"].device, priority=prio)
+        self._side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._side):
+            self._step_big(st, self._side.cuda_stream)
+        st["done"] = True
+
     def step(self):
         for p, v in self._small:
             g = self._grad_like_param(p)
@@ -72,20 +123,17 @@ class FusedAdam:
             self.opt.step()
         if not self._big:
             return
-        lib = _lib.load()
-        hp = self.param_groups[0] if self.opt is not None else self.defaults
-        lr, (b1, b2), eps, wd = hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"]
         stream = torch.cuda.current_stream().cuda_stream
+        joined = False
         for st in self._big:
-            g = self._grad_like_param(st["p"])
-            if g is None:
-                continue
-            gf = _flat_storage_view(torch.view_as_real(g) if g.is_complex() else g)
-            assert gf is not None and gf.dtype == torch.float32 and gf.numel() == st["flat"].numel()
-            st["step"] += 1
-            _lib.check(lib.mk_adam_step(st["flat"].data_ptr(), gf.data_ptr(), st["m"].data_ptr(), st["v"].data_ptr(),
-                                        gf.numel(), float(lr), float(b1), float(b2), float(eps), float(wd), st["step"], stream),
-                       "mk_adam_step")
+            if st["done"]:              # already under way on the side stream: the gradient stays alive until the join below
+                st["done"] = False
+                joined = True
+            else:
+                self._step_big(st, stream)
+            st["acc"] = 0
+        if joined:
+            torch.cuda.current_stream().wait_stream(self._side)
 
     def state_dict(self):
         return {"small": None if self.opt is None else self.opt.state_dict(),

@@ -502,6 +502,55 @@ def test_adam_step_matches_torch(dev):
         assert rel(a.cpu().numpy(), b.cpu().numpy()) < 1e-6
 
 
+def test_adam_overlapped_with_backward_is_the_same_update(dev):
+    """FusedAdam(overlap_backward=1) launches the update of a large tensor from its post-accumulate hook on a side stream
+    (under the rest of backward) and joins it in step(): parameters and moments must equal, bit for bit, those of the
+    optimizer that does everything in step() -- over several steps, with a tensor whose gradient arrives early in backward
+    (so later backward kernels overlap its update), a complex one, zero_grad in both modes and a skipped gradient."""
+    from makani_amd.optim import FusedAdam
+    torch.manual_seed(5)
+
+    def make():
+        torch.manual_seed(11)
+        a = torch.nn.Parameter(torch.randn(1100, 1001, device=dev))
+        b = torch.nn.Parameter(torch.randn(96, 96, 120, dtype=torch.complex64, device=dev))
+        c = torch.nn.Parameter(torch.randn(1001, 1300, device=dev))          # used first in forward: its gradient comes last
+        d = torch.nn.Parameter(torch.randn(64, device=dev))                  # small: torch's fused Adam
+        return [a, b, c, d]
+
+    def loss_fn(ps, x, z, use_b=True):
+        a, b, c, d = ps
+        h = torch.tanh(x @ c[:, :1100])                      # [32, 1100]
+        y = (h @ a) * 1e-2                                   # [32, 1001]
+        s = (torch.view_as_real(b * z) ** 2).mean() if use_b else 0.0
+        return (y ** 2).mean() + s + (d ** 2).sum() * 1e-3
+
+    xs = [torch.randn(32, 1001, device=dev) for _ in range(4)]
+    zs = [torch.randn(96, 96, 120, dtype=torch.complex64, device=dev) for _ in range(4)]
+    runs = []
+    for overlap in (0, 1):
+        ps = make()
+        opt = FusedAdam(ps, lr=1e-2, weight_decay=0.05, overlap_backward=overlap)
+        assert len(opt._big) == 3 and len(opt._small) == 1
+        for i in range(4):
+            opt.zero_grad(set_to_none=(i % 2 == 0))
+            loss = loss_fn(ps, xs[i], zs[i], use_b=(i != 2))       # step 2: the complex tensor gets no gradient at all
+            loss.backward()
+            if overlap:
+                assert any(st["done"] for st in opt._big)
+            opt.step()
+            assert not any(st["done"] for st in opt._big)
+        torch.cuda.synchronize()
+        runs.append(([p.detach().clone() for p in ps], [st["m"].clone() for st in opt._big], [st["v"].clone() for st in opt._big],
+                     [st["step"] for st in opt._big]))
+    for pa, pb in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(torch.view_as_real(pa) if pa.is_complex() else pa, torch.view_as_real(pb) if pb.is_complex() else pb)
+    for k in (1, 2):
+        for ta, tb in zip(runs[0][k], runs[1][k]):
+            assert torch.equal(ta, tb)
+    assert runs[0][3] == runs[1][3]
+
+
 def test_conv_kernels_reject_misaligned_and_odd_sizes(dev):
     """The bf16 1x1-conv kernels read 16-byte vectors: odd pixel counts and offset views whose base is not 16-byte
     aligned must come back as an error from the C ABI (never as a device fault), and aligned offset views must work.
