@@ -320,9 +320,10 @@ def main():
     net = SphericalFourierNeuralOperatorNet(**CONFIG).to(dev)
     mappings.sync_params(net)
     from makani_amd.optim import FusedAdam
-    # The update of a large tensor starts on a side stream as soon as backward has produced its gradient (optim.py): the
-    # HBM-bound Adam passes of the spectral weights run under the rest of backward.  MK_ADAM_OVERLAP=0: all of it in opt.step().
-    adam_overlap = int(os.environ.get("MK_ADAM_OVERLAP", "1"))
+    # MK_ADAM_OVERLAP=1: the update of a large tensor starts on a side stream as soon as backward has produced its gradient
+    # (optim.py).  Measured neutral on one GPU (44.57-44.85 ms/step off, 44.69-44.85 on, same box, alternating runs: the
+    # backward kernels running beside an Adam pass slow down by what the pass would have cost on its own), so it stays off.
+    adam_overlap = int(os.environ.get("MK_ADAM_OVERLAP", "0"))
     opt = FusedAdam(net.parameters(), lr=1e-4, overlap_backward=adam_overlap)
 
     B = world                                   # weak scaling: one sample per GPU

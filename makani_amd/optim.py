@@ -13,7 +13,8 @@ number as two reals, so every parameter is stepped through a real view of its st
 has been accumulated ``k`` times in this step (``k`` = backward passes per step: 1, or the number of micro-batches), so the
 HBM-bound streaming pass runs under the remaining backward kernels (which leave most of the HBM bandwidth idle) instead
 of after them; ``step()`` launches whatever is left and joins the side stream.  The arithmetic and the result are the same
-as without it.  Only valid when nothing is done to these gradients between backward and ``step()``: no gradient clipping
+as without it.  (On one MI355X the step time does not change: the backward kernels that run beside an Adam pass slow
+down by what the pass would have cost alone -- ``bench.py`` leaves it off.)  Only valid when nothing is done to these gradients between backward and ``step()``: no gradient clipping
 or scaling, no data-parallel averaging (the spectral weights are sharded, not shared, over the model-parallel groups, so
 ``reduce_shared_gradients`` does not touch them).  Under stream capture the hook does nothing (the captured graph ends with
 backward; the optimizer steps outside it, ``trainer.py:762-763``).
@@ -106,10 +107,7 @@ class FusedAdam:
         if torch.cuda.is_current_stream_capturing():
             return
         if self._side is None:
-            import os
-            # lowest priority the device offers: the update should fill what the backward kernels leave idle, not compete
-            prio = int(os.environ.get("MK_ADAM_STREAM_PRIORITY", "1"))
-            self._side = torch.cuda.Stream(device=st["p"].device, priority=prio)
+            self._side = torch.cuda.Stream(device=st["p"].device)    # gfx950 offers priorities (0, -1): 0 is the lowest
         self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side):
             self._step_big(st, self._side.cuda_stream)
