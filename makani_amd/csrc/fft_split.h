@@ -248,7 +248,9 @@ template <> struct OutVec<__hip_bfloat16> {
     }
 };
 
-template <int S, typename TOut>
+// WIDE: mode offsets of one tile may exceed 2^31 bytes (mode-major Fourier rows of a very large batch): 64-bit pointer
+// arithmetic per gather instead of 32-bit buffer offsets.
+template <int S, typename TOut, bool WIDE>
 __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
                                                                float scale0, float scale_m, float scale_h, XfLayout xl) {
@@ -292,16 +294,39 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
         const XfChan xc = xf_chan(xl, bc0, BC);
         const int jp0 = tl / G, g = tl - jp0 * G;
         const bool chan_ok = bc0 + g < BC;
-        // Every load is issued unconditionally (element 0 of xf where there is nothing to fetch) and nothing here consumes a
-        // loaded value: a conditional load into a pre-zeroed register became load + copy, and the copy made the compiler wait
-        // for the whole gather right here instead of after the FFT passes of the current tile.  The merge step masks.
-        const float2* base = xf + xc.pbase + (size_t)k * xl.sk * xc.BCx + (xc.bcx0 + g);
+        // Every load is issued unconditionally and nothing here consumes a loaded value: a conditional load into a pre-zeroed
+        // register became load + copy, and the copy made the compiler wait for the whole gather right here instead of after
+        // the FFT passes of the current tile.  The merge step masks.
+        if constexpr (!WIDE) {
+            // Raw buffer loads on a tile-uniform descriptor with 32-bit lane offsets that advance by one add per item; a lane
+            // with nothing to fetch gets an offset past the range and reads zeros.  (The pointer form below cost a 64-bit
+            // multiply chain -- four quarter-rate integer multiplies -- and an exec-mask branch per 8-byte load: 16 loads per
+            // thread and tile, a fifth of the kernel's VALU cycles.)
+            typedef unsigned int gf_u2 __attribute__((ext_vector_type(2)));
+            const float2* tbase = xf + xc.pbase + (size_t)k * xl.sk * xc.BCx + xc.bcx0;
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float2*>(tbase), 0, 0x7FFFFFFF, 0x00020000);
+            const unsigned mstride = (unsigned)xl.sm * (unsigned)xc.BCx * 8u;        // bytes from one mode to the next
+            unsigned offa = (unsigned)g * 8u + (unsigned)jp0 * mstride;
+            unsigned offb = (unsigned)g * 8u + (unsigned)(SH - jp0) * mstride;
+            const unsigned dstepb = (unsigned)STEP * mstride;
 #pragma unroll
-        for (int it = 0; it < PIT; ++it) {
-            const int jp = jp0 + STEP * it, j1 = SH - jp;
-            const bool oa = chan_ok && jp < NPAIR && jp < M, ob = chan_ok && jp < NPAIR && j1 < M;
-            xa[it] = *(oa ? base + (size_t)jp * xl.sm * xc.BCx : xf);
-            xb[it] = *(ob ? base + (size_t)j1 * xl.sm * xc.BCx : xf);
+            for (int it = 0; it < PIT; ++it) {
+                const int jp = jp0 + STEP * it, j1 = SH - jp;
+                const bool oa = chan_ok && jp < NPAIR && jp < M, ob = chan_ok && jp < NPAIR && j1 < M;
+                xa[it] = __builtin_bit_cast(float2, (gf_u2)__builtin_amdgcn_raw_buffer_load_b64(rs, oa ? offa : 0x80000000u, 0, 0));
+                xb[it] = __builtin_bit_cast(float2, (gf_u2)__builtin_amdgcn_raw_buffer_load_b64(rs, ob ? offb : 0x80000000u, 0, 0));
+                offa += dstepb;
+                offb -= dstepb;
+            }
+        } else {
+            const float2* base = xf + xc.pbase + (size_t)k * xl.sk * xc.BCx + (xc.bcx0 + g);
+#pragma unroll
+            for (int it = 0; it < PIT; ++it) {
+                const int jp = jp0 + STEP * it, j1 = SH - jp;
+                const bool oa = chan_ok && jp < NPAIR && jp < M, ob = chan_ok && jp < NPAIR && j1 < M;
+                xa[it] = *(oa ? base + (size_t)jp * xl.sm * xc.BCx : xf);
+                xb[it] = *(ob ? base + (size_t)j1 * xl.sm * xc.BCx : xf);
+            }
         }
     };
     gather(tile, tid);
@@ -438,12 +463,18 @@ int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, i
     constexpr int G = SNSUB / S;
     const dim3 grid(split_grid(mk::ceil_div(bc, G) * (long long)nlat));
     const size_t lds = sizeof(float2) * SLDS_F2;
-    if (x_dtype == 0)
-        hipLaunchKernelGGL((irfft_split_kernel<S, float>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (float*)x,
-                           (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl);
-    else
-        hipLaunchKernelGGL((irfft_split_kernel<S, __hip_bfloat16>), grid, dim3(STHREADS), lds, st, (const float2*)xf,
-                           (__hip_bfloat16*)x, (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl);
+    // 32-bit mode offsets inside a tile's buffer descriptor: (240 modes + one row of channels) * 8 bytes must stay below 2^31
+    const long long bcx = g_xl.Cp ? (long long)g_xl.Bn * g_xl.Cp : (long long)bc;
+    const bool wide = ((long long)SH * g_xl.sm + 1) * bcx * 8 >= (1LL << 31);
+#define MK_IRFFT_LAUNCH(T, W)                                                                                          \
+    hipLaunchKernelGGL((irfft_split_kernel<S, T, W>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,            \
+                       (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl)
+    if (x_dtype == 0) {
+        if (wide) MK_IRFFT_LAUNCH(float, true); else MK_IRFFT_LAUNCH(float, false);
+    } else {
+        if (wide) MK_IRFFT_LAUNCH(__hip_bfloat16, true); else MK_IRFFT_LAUNCH(__hip_bfloat16, false);
+    }
+#undef MK_IRFFT_LAUNCH
     return 0;
 }
 
