@@ -71,6 +71,7 @@ struct PceParams {
     long long P, tiles_per_b, ntiles;
     unsigned long long* dbg;       // MK_PCE_DBG: s_memtime stamps of workgroup 0 (8 waves x 64 slots), else null
     int exp;                       // MK_PCE_EXP ablations (wrong results): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no X DMA
+    int nt;                        // output rows leave with nontemporal stores (streaming kernel only)
 };
 
 // ---- GELU (exact erf form, makani uses nn.GELU()) on the VALU budget of an epilogue --------------------------
@@ -247,8 +248,15 @@ __device__ __forceinline__ void pce_epilogue(const PceParams& p, f32x16 (&acc)[T
         wait_lgkm<0>();
         const int m0 = m_first + 32 * t + ea.row_lin;
         if (px_ok) {
-            if (m0 < p.M) *reinterpret_cast<u32x4*>(out + tile_base + (long long)m0 * p.P + ea.px_lin) = a;
-            if (m0 + 16 < p.M) *reinterpret_cast<u32x4*>(out + tile_base + (long long)(m0 + 16) * p.P + ea.px_lin) = b;
+            u32x4* d0 = reinterpret_cast<u32x4*>(out + tile_base + (long long)m0 * p.P + ea.px_lin);
+            u32x4* d1 = reinterpret_cast<u32x4*>(out + tile_base + (long long)(m0 + 16) * p.P + ea.px_lin);
+            if (p.nt) {
+                if (m0 < p.M) __builtin_nontemporal_store(a, d0);
+                if (m0 + 16 < p.M) __builtin_nontemporal_store(b, d1);
+            } else {
+                if (m0 < p.M) *d0 = a;
+                if (m0 + 16 < p.M) *d1 = b;
+            }
         }
     };
     auto stage = [&](const float (&v)[16]) {            // accumulator layout -> staging tile
@@ -1227,6 +1235,13 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
         p.ntiles = tiles_per_b * batch;
         p.dbg = pce_dbg_buffer();
         p.exp = pexp;
+        {   // MK_PCE_NT: 0 plain stores, 1 nontemporal always (default), n > 1: nontemporal when a field row has at least n pixels.
+            // Measured (tools/pce_bench.py, alternating runs on one box): 384 -> 384 at 721x1440 0.493 -> 0.476 ms, with the skip
+            // add at 240x480 0.076 -> 0.068, fc1 + bias + GELU + pre-activation at 240x480 0.163 -> 0.152, the full-resolution
+            // fc1 / fc2 launches unchanged; the step 44.57 / 44.65 -> 44.46 / 44.49 ms.
+            static const long long nt_rule = [] { const char* e = getenv("MK_PCE_NT"); return e ? atoll(e) : 1LL; }();
+            p.nt = nt_rule == 1 || (nt_rule > 1 && P >= nt_rule);
+        }
         bool done = false;
         // weights resident in registers when they fit (K <= 384, 384-row halves): MK_PCE_WS=0 keeps the streaming kernel
         const int use_ws = [] { const char* e = getenv("MK_PCE_WS"); return e ? atoi(e) : 0; }();   // 0 never (default), 1 where the microbenchmark says it pays, 2 wherever it fits

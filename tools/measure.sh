@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round measurement set (run on the GPU box from the repo root): bench line, rocprofv3 kernel stats, PMC traffic.
-# usage: bash tools/measure.sh <tag>      -> gpurun_out/<tag>_bench.json, gpurun_out/<tag>_prof/, gpurun_out/<tag>_traffic/
+# usage: bash tools/measure.sh <tag>      -> gpurun_out/<tag>_bench.json, <tag>_kernel_stats.txt, <tag>_traffic.json, <tag>_pmc_util.json
 set -o pipefail
 tag=${1:-rXX}
 export TMPDIR=/tmp
@@ -16,3 +16,9 @@ for c in FETCH_SIZE WRITE_SIZE; do
 done
 python3 tools/traffic_summary.py $out/${tag}_traffic > $out/${tag}_traffic.json
 echo "traffic summary done"
+for c in MfmaUtil SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE; do
+  rocprofv3 --pmc $c --output-format csv -d $out/${tag}_traffic/pmc_$c -o run -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > $out/${tag}_pmc_$c.log 2>&1 || exit 4
+  echo "pmc $c done"
+done
+python3 tools/util_summary.py $out/${tag}_traffic > $out/${tag}_pmc_util.json
+echo "utilisation summary done"
