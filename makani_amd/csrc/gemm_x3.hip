@@ -438,8 +438,21 @@ __device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
-                if (row < rvalid)
+                if (row < rvalid) {
+#ifndef MK_X3_PLAIN_STORE
+                    // nontemporal: the streamed output does not push the re-used panels (Legendre tile images, dhconv operands)
+                    // out of L2.  Isolated launches, same box: Legendre 0.120 / 0.107 -> 0.109 / 0.094 ms at 240 latitudes,
+                    // 0.288 / 0.289 -> 0.283 / 0.272 at 721; dhconv wgrad 0.211 -> 0.203; dhconv forward / dgrad unchanged.
+                    // (Nontemporal LOADS of the streamed operand were measured too: 8-13 % slower.)
+                    typedef float x3_f2 __attribute__((ext_vector_type(2)));
+                    x3_f2 v2;
+                    v2[0] = acc[a][0][r];
+                    v2[1] = acc[a][1][r];
+                    __builtin_nontemporal_store(v2, reinterpret_cast<x3_f2*>(cbase + (long long)row * ldc + col));
+#else
                     *reinterpret_cast<float2*>(cbase + (long long)row * ldc + col) = make_float2(acc[a][0][r], acc[a][1][r]);
+#endif
+                }
             }
     }
 }

@@ -72,6 +72,7 @@ struct PceParams {
     unsigned long long* dbg;       // MK_PCE_DBG: s_memtime stamps of workgroup 0 (8 waves x 64 slots), else null
     int exp;                       // MK_PCE_EXP ablations (wrong results): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no X DMA
     int nt;                        // output rows leave with nontemporal stores (streaming kernel only)
+    int xcd_runs;                  // tile order: each XCD takes a contiguous run of the 256-tile window (see phys_tile)
 };
 
 // ---- GELU (exact erf form, makani uses nn.GELU()) on the VALU budget of an epilogue --------------------------
@@ -421,8 +422,19 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         bool lane_ok;                 // this lane's pixels are inside the field
         bool active;
     };
-    auto x_target = [&](int tile, int phase, int region) {
+    // Work index -> pixel tile.  Workgroup w runs on XCD w % 8; with the plain order (tile = work index) neighbouring tiles
+    // sit on different XCDs, and where a field row is not a multiple of 128 bytes (721 x 1440 bf16: 64 mod 128) the
+    // 128-byte lines at a tile's edges are shared with the neighbours: each half is fetched / written back by another L2.
+    // With xcd_runs the eight XCDs take contiguous runs of W / 8 tiles of each W-tile window (W = gridDim.x), so a shared
+    // line meets both of its halves in one L2 (the forward / inverse FFT do the same with tile pairs, fft_split.h).
+    auto phys_tile = [&](int t) {
+        const int W = (int)gridDim.x, base = t - (int)blockIdx.x;
+        if (!p.xcd_runs || base + W > ntiles) return t;        // the last, partial window keeps the plain order
+        return base + ((int)blockIdx.x & 7) * (W >> 3) + ((int)blockIdx.x >> 3);
+    };
+    auto x_target = [&](int work, int phase, int region) {
         XTarget t;
+        const int tile = phys_tile(work);
         const int b = tile / tiles_per_b;
         const int l = opaque_lane();
         const int x_chunk = ((l & 15) - 4 * ((l >> 4) & 3)) & 15;   // global chunk this lane fetches
@@ -556,8 +568,9 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         const bool last_pass = pass + 1 == p.npass;
         const int next_tile = last_pass ? tile + (int)gridDim.x : tile;
         const bool item_after = next_tile < ntiles;
-        const int b = tile / tiles_per_b;
-        const long long n0 = (long long)(tile - b * tiles_per_b) * PN;
+        const int ptile = phys_tile(tile);
+        const int b = ptile / tiles_per_b;
+        const long long n0 = (long long)(ptile - b * tiles_per_b) * PN;
         f32x16 acc[TH];
         stamp();   // 0: tile start
         if (si_next) si_next = false;               // the stream's "next item" is this item now
@@ -1142,7 +1155,11 @@ static int pce_launch(const PceParams& p, hipStream_t st) {
         return n > 0 ? n : 256;
     }();
     const long long grid = p.ntiles < ncu ? p.ntiles : ncu;
-    hipLaunchKernelGGL((pce_kernel<KSP, NPH, TH, HAS_IN>), dim3((unsigned)grid), dim3(PT), LDS, st, p);
+    PceParams q = p;
+    // MK_PCE_XCD_RUNS: 0 plain tile order, 1 (default) XCD runs where rows are not whole 128-byte lines, 2 always
+    static const int runs_rule = [] { const char* e = getenv("MK_PCE_XCD_RUNS"); return e ? atoi(e) : 1; }();
+    q.xcd_runs = grid % 8 == 0 && (runs_rule == 2 || (runs_rule == 1 && (p.P * 2) % 128 != 0));
+    hipLaunchKernelGGL((pce_kernel<KSP, NPH, TH, HAS_IN>), dim3((unsigned)grid), dim3(PT), LDS, st, q);
     return 0;
 }
 
@@ -1242,6 +1259,7 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
             static const long long nt_rule = [] { const char* e = getenv("MK_PCE_NT"); return e ? atoll(e) : 1LL; }();
             p.nt = nt_rule == 1 || (nt_rule > 1 && P >= nt_rule);
         }
+        p.xcd_runs = 0;     // set by pce_launch from the grid it picks
         bool done = false;
         // weights resident in registers when they fit (K <= 384, 384-row halves): MK_PCE_WS=0 keeps the streaming kernel
         const int use_ws = [] { const char* e = getenv("MK_PCE_WS"); return e ? atoi(e) : 0; }();   // 0 never (default), 1 where the microbenchmark says it pays, 2 wherever it fits
