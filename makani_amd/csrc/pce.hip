@@ -73,6 +73,8 @@ struct PceParams {
     int exp;                       // MK_PCE_EXP ablations (wrong results): 1 no epilogue, 2 no MFMA, 4 no weight DMA, 8 no X DMA
     int nt;                        // output rows leave with nontemporal stores (streaming kernel only)
     int xcd_runs;                  // tile order: each XCD takes a contiguous run of the 256-tile window (see phys_tile)
+    int split;                     // streaming kernel, two passes: the passes of a tile go to a PAIR of workgroups (see the kernel)
+    int Mb;                        // rows of one batch item (batch stride of y / addend / aux / rowstats); = M on entry
 };
 
 // ---- GELU (exact erf form, makani uses nn.GELU()) on the VALU budget of an epilogue --------------------------
@@ -394,6 +396,30 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     constexpr int ngroup_tile = NPH * NG;
     const int ntiles = (int)p.ntiles, tiles_per_b = (int)p.tiles_per_b;
 
+    // Two passes (M > 64 TH rows) on ONE workgroup fetch the X tile twice, and at 721 x 1440 the second fetch came from HBM again
+    // (PMC: 1.68 GB read per 384 -> 768 launch for 0.80 GB of X -- between the two fetches 9 MB stream through the XCD's 4 MB L2).
+    // With `split` the two passes of a tile go to workgroups w and w + 8 instead: same XCD, same tile sequence, in step with
+    // each other, so the second request for a line meets the first in L2.  Each workgroup then is a one-pass kernel on its
+    // half of the rows: the row-indexed pointers are advanced by the half's first row and everything below sees npass = 1.
+    int wg = (int)blockIdx.x, nwg = (int)gridDim.x;
+    if (p.split) {
+        const int h = (wg >> 3) & 1;
+        wg = ((wg >> 4) << 3) | (wg & 7);
+        nwg >>= 1;
+        const int r0 = h * 64 * TH;                    // first row of this half
+        p.wimg += h * p.img_per_pass;
+        if (r0 < p.nbias) { p.bias += r0; p.nbias -= r0; } else { p.bias += p.nbias - 1; p.nbias = 1; }
+        const long long roff = (long long)r0 * p.P;
+        p.y += roff;
+        if (p.aux_out) p.aux_out += roff;
+        if (p.addend) p.addend += roff;
+        if (p.aux_in) p.aux_in += roff;
+        if (p.aff) p.aff += 2 * r0;
+        if (p.rowstats) p.rowstats += 2 * r0;
+        p.M -= r0;                                     // rows left from r0 on (the first half never looks past its 64 TH rows)
+        p.npass = 1;
+    }
+
     // Per-lane addressing of the X fragments and of the epilogue is recomputed from an opaque copy of the lane id where
     // it is used (once per tile): kept live across the MFMA loop it would be spilled, and a scratch reload inside the
     // epilogue waits behind the stores queued before it.
@@ -428,9 +454,9 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     // With xcd_runs the eight XCDs take contiguous runs of W / 8 tiles of each W-tile window (W = gridDim.x), so a shared
     // line meets both of its halves in one L2 (the forward / inverse FFT do the same with tile pairs, fft_split.h).
     auto phys_tile = [&](int t) {
-        const int W = (int)gridDim.x, base = t - (int)blockIdx.x;
+        const int W = nwg, base = t - wg;
         if (!p.xcd_runs || base + W > ntiles) return t;        // the last, partial window keeps the plain order
-        return base + ((int)blockIdx.x & 7) * (W >> 3) + ((int)blockIdx.x >> 3);
+        return base + (wg & 7) * (W >> 3) + (wg >> 3);
     };
     auto x_target = [&](int work, int phase, int region) {
         XTarget t;
@@ -462,7 +488,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         return cnt;
     };
 
-    int tile = blockIdx.x;
+    int tile = wg;
     int g = 0;           // running group counter: group g lives in ring buffer g % 3
     int gi = 0;          // groups issued so far
     int landed = 0;      // groups known to have landed (drained before the last epilogue)
@@ -489,7 +515,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     for (int i = tid; i < p.npass * 64 * TH; i += PT) lds_write_b32(p.bias_lds + 4 * i, p.bias[min(i, p.nbias - 1)]);
     wait_lgkm<0>();
     if (tile < ntiles) {
-        const bool after = p.npass > 1 || tile + (int)gridDim.x < ntiles;
+        const bool after = p.npass > 1 || tile + nwg < ntiles;
         issue_next_group(after);
         issue_next_group(after);
         for (int ph = 0; ph < NREG; ++ph) {
@@ -551,8 +577,8 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                             b += b1;
                         }
                         if (m < p.M) {
-                            atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2, (double)a);
-                            atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2 + 1, (double)b);
+                            atomicAdd(p.rowstats + ((long long)rs_b * p.Mb + m) * 2, (double)a);
+                            atomicAdd(p.rowstats + ((long long)rs_b * p.Mb + m) * 2 + 1, (double)b);
                         }
                     }
                 }
@@ -562,11 +588,11 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             for (int t = 0; t < TH; ++t) rs1[i][t] = rs2[i][t] = 0.f;
         }
     };
-    for (; tile < ntiles; tile += gridDim.x)
+    for (; tile < ntiles; tile += nwg)
     for (int pass = 0; pass < p.npass; ++pass) {
         // the item after this one: the next pass over the same tile, or the first pass over the next tile
         const bool last_pass = pass + 1 == p.npass;
-        const int next_tile = last_pass ? tile + (int)gridDim.x : tile;
+        const int next_tile = last_pass ? tile + nwg : tile;
         const bool item_after = next_tile < ntiles;
         const int ptile = phys_tile(tile);
         const int b = ptile / tiles_per_b;
@@ -681,8 +707,8 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             float ts1[TH], ts2[TH];
 #pragma unroll
             for (int t = 0; t < TH; ++t) ts1[t] = ts2[t] = 0.f;
-            pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.M * p.P + px0,
-                                     px0 + ea.px_lin < p.P, gmask, ts1, ts2, b * p.M);
+            pce_epilogue<TH, HAS_IN>(p, acc, ea, pass * 64 * TH + mh * 32 * TH, ml, (long long)b * p.Mb * p.P + px0,
+                                     px0 + ea.px_lin < p.P, gmask, ts1, ts2, b * p.Mb);
             if (p.rowstats) {
                 if (pass == 0) {
 #pragma unroll
@@ -1158,7 +1184,11 @@ static int pce_launch(const PceParams& p, hipStream_t st) {
     PceParams q = p;
     // MK_PCE_XCD_RUNS: 0 plain tile order, 1 (default) XCD runs where rows are not whole 128-byte lines, 2 always
     static const int runs_rule = [] { const char* e = getenv("MK_PCE_XCD_RUNS"); return e ? atoi(e) : 1; }();
-    q.xcd_runs = grid % 8 == 0 && (runs_rule == 2 || (runs_rule == 1 && (p.P * 2) % 128 != 0));
+    // MK_PCE_SPLIT: 0 both passes of a wide layer on one workgroup, 1 (default) on workgroup pairs w, w + 8 (see the kernel)
+    static const int split_rule = [] { const char* e = getenv("MK_PCE_SPLIT"); return e ? atoi(e) : 1; }();
+    q.split = split_rule && p.npass == 2 && grid == ncu && grid % 16 == 0 && p.ntiles >= grid;
+    const long long wgs_per_pass = q.split ? grid / 2 : grid;
+    q.xcd_runs = wgs_per_pass % 8 == 0 && (runs_rule == 2 || (runs_rule == 1 && (p.P * 2) % 128 != 0));
     hipLaunchKernelGGL((pce_kernel<KSP, NPH, TH, HAS_IN>), dim3((unsigned)grid), dim3(PT), LDS, st, q);
     return 0;
 }
@@ -1260,6 +1290,8 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
             p.nt = nt_rule == 1 || (nt_rule > 1 && P >= nt_rule);
         }
         p.xcd_runs = 0;     // set by pce_launch from the grid it picks
+        p.split = 0;        // likewise
+        p.Mb = M;
         bool done = false;
         // weights resident in registers when they fit (K <= 384, 384-row halves): MK_PCE_WS=0 keeps the streaming kernel
         const int use_ws = [] { const char* e = getenv("MK_PCE_WS"); return e ? atoi(e) : 0; }();   // 0 never (default), 1 where the microbenchmark says it pays, 2 wherever it fits

@@ -29,11 +29,13 @@ def engine_variant(request, monkeypatch):
 
 
 # (M, K, P, batch): production channel counts on small pixel counts; ragged pixel tiles (P % 128 != 0), partial row
-# tiles (73), two passes (768 rows), two K phases (768 -> 384), tiny test-net sizes
+# tiles (73), two passes (768 rows), two K phases (768 -> 384), tiny test-net sizes; the last two give a two-pass layer at
+# least one tile per workgroup, which is when the passes of a tile go to workgroup PAIRS (MK_PCE_SPLIT): whole and ragged
+# second half, two batch items
 SHAPES = [(384, 384, 1024, 1), (384, 384, 1000, 2), (768, 384, 520, 1), (384, 768, 776, 1), (384, 73, 640, 1),
           (200, 130, 72, 2), (384, 256, 64 * 300 + 24, 2), (768, 100, 64 * 520, 1),
           (73, 384, 264, 3), (73, 73, 1048, 1), (16, 8, 2048, 2), (3, 16, 72, 1), (96, 40, 392, 1), (128, 200, 136, 1),
-          (200, 500, 256, 1)]
+          (200, 500, 256, 1), (768, 384, 128 * 140 + 40, 2), (500, 100, 128 * 260 + 8, 1)]
 
 
 @pytest.mark.parametrize("M,K,P,B", SHAPES)
@@ -52,7 +54,8 @@ def test_pce_plain_gemm(dev, M, K, P, B):
 
 
 @pytest.mark.parametrize("M,K,P,B", [(384, 384, 1000, 2), (768, 384, 520, 1), (73, 384, 264, 3), (16, 8, 2048, 2),
-                                     (384, 73, 64 * 280 + 8, 2), (300, 200, 64 * 600, 1)])
+                                     (384, 73, 64 * 280 + 8, 2), (300, 200, 64 * 600, 1), (768, 384, 128 * 140 + 40, 2),
+                                     (500, 384, 128 * 130 + 8, 2)])
 def test_pce_epilogues(dev, M, K, P, B):
     from makani_amd import ops
     torch.manual_seed(11)
@@ -126,7 +129,7 @@ def test_instance_norm_with_given_sums(dev):
     assert _rel(c, a) < 1e-5
 
 
-@pytest.mark.parametrize("M,K,P,B", [(384, 384, 1000, 2), (73, 40, 264, 3), (768, 384, 520, 1)])
+@pytest.mark.parametrize("M,K,P,B", [(384, 384, 1000, 2), (73, 40, 264, 3), (768, 384, 520, 1), (768, 384, 128 * 140 + 40, 2)])
 def test_pce_addend_affine(dev, M, K, P, B):
     """The addend enters as a[row] * addend + b[row]: the apply pass of an instance norm folded into the epilogue."""
     from makani_amd import ops
