@@ -85,7 +85,8 @@ class _PointwiseConv(torch.autograd.Function):
 def _row_sums(t3):
     """sum over (batch, pixels) of a [B, C, P] field -> fp32 [C] (the HIP row-sum pass of the instance norm)."""
     from . import ops
-    return ops.row_sums(t3).view(t3.shape[0], t3.shape[1]).sum(0)
+    r = ops.row_sums(t3).view(t3.shape[0], t3.shape[1])
+    return r[0] if r.shape[0] == 1 else r.sum(0)      # one batch item: nothing to add up (saves a launch per bias gradient)
 
 
 class _PceConv(torch.autograd.Function):
@@ -230,7 +231,11 @@ class _PceMLP(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw1 = ops.conv1x1_wgrad_raw(gpre, x3).to(w1.dtype)
         if need_gb1:
-            gb1 = (gsum.view(gy.shape[0], -1, 2)[..., 0].sum(0) if fused_gb1 else _row_sums(gpre)).to(b1_dtype)
+            if fused_gb1:
+                g1 = gsum.view(gy.shape[0], -1, 2)[..., 0]
+                gb1 = (g1[0] if g1.shape[0] == 1 else g1.sum(0)).to(b1_dtype)
+            else:
+                gb1 = _row_sums(gpre).to(b1_dtype)
         if ctx.needs_input_grad[3]:
             gw2 = ops.conv1x1_wgrad_raw(gy, h).to(w2.dtype)
         if b2_info is not None and ctx.needs_input_grad[4]:

@@ -733,7 +733,8 @@ def instance_norm_backward(x, gy, stats, wf, bf, fuse_gelu=False, group=None, co
         local = ws.clone()
         torch.distributed.all_reduce(ws, group=group)
         run(2)
-    sums = local.view(B, C, 2).sum(0)
+    sums = local.view(B, C, 2)
+    sums = sums[0] if B == 1 else sums.sum(0)
     return gx, sums[:, 1], sums[:, 0]
 
 
