@@ -26,8 +26,8 @@ from torch.utils.checkpoint import checkpoint
 from . import comm
 from .distributed import DistributedInverseRealFFT2, DistributedInverseRealSHT, DistributedRealFFT2, DistributedRealSHT
 from .layer_norm import DistributedInstanceNorm2d
-from .layers import (Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _is_exact_gelu,
-                     conv_plus_instance_norm)
+from .layers import (Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _engine_field,
+                     _is_exact_gelu, conv_plus_instance_norm)
 from .sht import InverseRealSHT, RealSHT
 from .spectral_convolution import FactorizedSpectralConv, SpectralAttention, SpectralConv
 
@@ -294,6 +294,11 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
         return x
 
     def forward(self, x):
+        if self.big_skip and self.out_shape == self.inp_shape and x.dtype == torch.float32 and x.dim() == 4:
+            # the input feeds the encoder AND the big skip: cast it for the bf16 engine once, not once per consumer
+            x3 = _engine_field(x)
+            if x3 is not None and x3.dtype != x.dtype:
+                x = x3.view(x.shape)
         skip_in = self._big_skip_input(x) if self.big_skip else None
         x = checkpoint(self.encoder, x, use_reentrant=False) if self.checkpointing >= 1 else self.encoder(x)
         if hasattr(self, "pos_embed"):
