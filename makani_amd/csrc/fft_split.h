@@ -255,8 +255,11 @@ template <> struct OutVec<__hip_bfloat16> {
 
 // WIDE: mode offsets of one tile may exceed 2^31 bytes (mode-major Fourier rows of a very large batch): 64-bit pointer
 // arithmetic per gather instead of 32-bit buffer offsets.
-template <int S, typename TOut, bool WIDE>
-__global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
+// PERSIST = 1: workgroups walk the tiles with the next tile's mode gather in flight under the current tile's passes (32 prefetch
+// registers: 167 VGPRs, two workgroups per CU).  PERSIST = 0: one tile per workgroup, nothing prefetched, the pass twiddles loaded
+// after the merge step -- registers for five waves per SIMD, i.e. three workgroups per CU covering each other like the forward kernel.
+template <int S, typename TOut, bool WIDE, int PERSIST>
+__global__ __launch_bounds__(STHREADS, PERSIST ? 3 : 5) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
                                                                float scale0, float scale_m, float scale_h, XfLayout xl) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2;
@@ -271,13 +274,17 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
         while (i < total16 && pair_tile(i) >= total) i += (int)gridDim.x;
         return i;
     };
-    int sched = next_valid(blockIdx.x);
+    int sched = PERSIST ? next_valid(blockIdx.x) : (int)blockIdx.x;
     if (sched >= total16) return;
     int tile = pair_tile(sched);
+    if (!PERSIST && tile >= total) return;
 
     float2 tw15[15];
+    auto load_tw15 = [&]() {
 #pragma unroll
-    for (int r = 0; r < 15; ++r) tw15[r] = tw[((tid & 15) * r) * S];
+        for (int r = 0; r < 15; ++r) tw15[r] = tw[((tid & 15) * r) * S];
+    };
+    if constexpr (PERSIST != 0) load_tw15();
 
     float2 wfirst[S];        // exp(-2 pi i s' (tid / G) / N), s' = S, 1, 2: merge-step twiddles of this thread's first item
     wfirst[0] = tw2[S * (tid / G)];
@@ -375,8 +382,9 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
             if (jp != 0 && j1 != jp) zs[j1] = make_float2(e.x + t.y, e.y - t.x);
         }
     }
+    if constexpr (PERSIST == 0) load_tw15();      // issued before the barrier: the latency sits under the wait for the other waves
     __syncthreads();
-    const int next = next_valid(sched + (int)gridDim.x);
+    const int next = PERSIST ? next_valid(sched + (int)gridDim.x) : total16;
     if (next < total16) gather(pair_tile(next), opaque(tid));
     split_passes(lds, tl, S, tw15);
     __syncthreads();
@@ -421,12 +429,19 @@ __global__ __launch_bounds__(STHREADS, 3) void irfft_split_kernel(const float2* 
   }
 }
 
-// persistent launch: MK_FFT_WGS workgroups per CU (default 2) walk the tiles; 0 = one workgroup per tile
-static inline unsigned split_grid(long long tiles) {
+// Inverse kernel: MK_FFT_WGS = n > 0 launches n persistent workgroups per CU (PERSIST = 1); 0 (default) one workgroup per tile
+// (PERSIST = 0).  Measured on one box, alternating: bf16 rows out at 721 x 1440 0.595 -> 0.505 ms, at 240 x 480 0.094 -> 0.074 ms
+// (2 persistent workgroups -> one per tile), the step 44.31 / 44.44 -> 43.80 / 43.77 ms: three workgroups per CU covering
+// each other beat two with a register prefetch, as in the forward kernel.
+static inline int fft_wgs_per_cu() {
     static const int per_cu = [] {
         const char* e = getenv("MK_FFT_WGS");
-        return e ? atoi(e) : 2;
+        return e ? atoi(e) : 0;
     }();
+    return per_cu;
+}
+static inline unsigned split_grid(long long tiles) {
+    const int per_cu = fft_wgs_per_cu();
     static const int cus = [] {
         int dev = 0, v = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 256;
@@ -471,13 +486,14 @@ int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, i
     // 32-bit mode offsets inside a tile's buffer descriptor: (240 modes + one row of channels) * 8 bytes must stay below 2^31
     const long long bcx = g_xl.Cp ? (long long)g_xl.Bn * g_xl.Cp : (long long)bc;
     const bool wide = ((long long)SH * g_xl.sm + 1) * bcx * 8 >= (1LL << 31);
-#define MK_IRFFT_LAUNCH(T, W)                                                                                          \
-    hipLaunchKernelGGL((irfft_split_kernel<S, T, W>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,            \
+    const bool persist = wide || fft_wgs_per_cu() > 0;      // MK_FFT_WGS=0: the one-tile-per-workgroup variant
+#define MK_IRFFT_LAUNCH(T, W, PS)                                                                                      \
+    hipLaunchKernelGGL((irfft_split_kernel<S, T, W, PS>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,        \
                        (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl)
     if (x_dtype == 0) {
-        if (wide) MK_IRFFT_LAUNCH(float, true); else MK_IRFFT_LAUNCH(float, false);
+        if (wide) MK_IRFFT_LAUNCH(float, true, 1); else if (persist) MK_IRFFT_LAUNCH(float, false, 1); else MK_IRFFT_LAUNCH(float, false, 0);
     } else {
-        if (wide) MK_IRFFT_LAUNCH(__hip_bfloat16, true); else MK_IRFFT_LAUNCH(__hip_bfloat16, false);
+        if (wide) MK_IRFFT_LAUNCH(__hip_bfloat16, true, 1); else if (persist) MK_IRFFT_LAUNCH(__hip_bfloat16, false, 1); else MK_IRFFT_LAUNCH(__hip_bfloat16, false, 0);
     }
 #undef MK_IRFFT_LAUNCH
     return 0;
