@@ -140,8 +140,8 @@ struct PresplitStager {
 
 // The same constant operand kept as fp32 tiles ([128 rows][32 k] floats = 16 KB per k-step instead of 24 KB) and split
 // while staging: a third less panel traffic through the load path for 88 more VALU operations per thread and k-step
-// (MK_X3_TABLE=f32).  Measured 2 % faster than the pre-split image on all four production launches -- within
-// noise, so the pre-split image stays the default; the smaller tables (2/3 of the bytes) are the reason to use it.
+// (the default; MK_X3_TABLE=presplit selects the image above).  2 % faster than the pre-split image on all four production
+// launches in isolation and 0 - 0.2 ms per step, with two thirds of the table bytes.
 struct F32TileStager {
     const char* base;
     typedef float4 Regs[4];
@@ -668,7 +668,10 @@ __global__ void legendre_x3_split_kernel(const float* __restrict__ tab, uint16_t
 }
 
 static int x3_f32tiles() {
-    static const int v = [] { const char* e = getenv("MK_X3_TABLE"); return (e && e[0] == 'f') ? 1 : 0; }();
+    // fp32 tiles split while staging by default (MK_X3_TABLE=presplit: the bf16x3 image): in the step 45.07 / 45.08 ->
+    // 44.82 / 44.88 ms on one box, within noise on another (alternating runs), and two thirds of the image bytes; the results are bit-identical
+    // (the same exact split, done earlier or later)
+    static const int v = [] { const char* e = getenv("MK_X3_TABLE"); return (e && e[0] == 'p') ? 0 : 1; }();
     return v;
 }
 
