@@ -156,7 +156,8 @@ class _PceConvNormAdd(torch.autograd.Function):
         if bias_dtype is not None and ctx.needs_input_grad[2]:
             gb = _row_sums(gy).to(bias_dtype)
         gz, gnw, gnb = ops.instance_norm_backward(z4, gy.view(B, C, H, W), stats, wf if nw_dtype is not None else None,
-                                                  bf if nb_dtype is not None else None, False, group, cnt)
+                                                  bf if nb_dtype is not None else None, False, group, cnt,
+                                                  grad_dtype=nw_dtype if (nw_dtype is not None and nw_dtype == nb_dtype) else None)
         return (gx, gw, gb, gz, None, gnw.to(nw_dtype) if nw_dtype is not None else None,
                 gnb.to(nb_dtype) if nb_dtype is not None else None, None, None, None)
 

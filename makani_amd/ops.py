@@ -706,13 +706,15 @@ class _InstanceNorm(torch.autograd.Function):
     def backward(ctx, gy):
         x, stats, wf, bf = ctx.saved_tensors
         has_w, has_b, fuse, wdt, bdt, group, cnt = ctx.cfg
-        gx, gw, gb = instance_norm_backward(x, gy, stats, wf if has_w else None, bf if has_b else None, fuse, group, cnt)
+        gx, gw, gb = instance_norm_backward(x, gy, stats, wf if has_w else None, bf if has_b else None, fuse, group, cnt,
+                                            grad_dtype=wdt if (has_w and has_b and wdt == bdt) else None)
         return gx, gw.to(wdt) if has_w else None, gb.to(bdt) if has_b else None, None, None, None, None, None
 
 
-def instance_norm_backward(x, gy, stats, wf, bf, fuse_gelu=False, group=None, count=None):
+def instance_norm_backward(x, gy, stats, wf, bf, fuse_gelu=False, group=None, count=None, grad_dtype=None):
     """Backward of the (optionally GELU-fused) instance norm from its saved ``stats`` [B * C, 2] = (mean, rstd):
-    returns (gx, local weight-gradient sums [C] fp64, local bias-gradient sums [C] fp64)."""
+    returns (gx, local weight-gradient sums [C], local bias-gradient sums [C]) -- the sums in fp64, or, with ``grad_dtype``,
+    cast to it by ONE copy into a ``[2, C]`` buffer whose rows are the two (contiguous) results."""
     B, C, H, W = x.shape
     gy = gy.contiguous()
     gx = torch.empty_like(x)
@@ -735,6 +737,10 @@ def instance_norm_backward(x, gy, stats, wf, bf, fuse_gelu=False, group=None, co
         run(2)
     sums = local.view(B, C, 2)
     sums = sums[0] if B == 1 else sums.sum(0)
+    if grad_dtype is not None:
+        out = torch.empty(2, C, dtype=grad_dtype, device=x.device)
+        out.copy_(sums.t())
+        return gx, out[1], out[0]
     return gx, sums[:, 1], sums[:, 0]
 
 
