@@ -226,19 +226,6 @@ int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const float* wrow
  * in MLP / EncoderDecoder / skip connections (layers.py:95-128,158-183; sfnonet.py:207,463). */
 int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
                      void* stream);
-/* The same contract, output-stationary: every workgroup keeps a 192 x 384 block of gw in registers for the whole launch and
- * streams the operand rows through LDS once (csrc/wgrad_os.hip); gw is reached by one round of atomics at the end. */
-int mk_conv1x1_wgrad_os(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
-                        void* stream);
-
-/* Forward / data-gradient GEMM of the same convolution on bf16 NCHW fields:
- *   y[b][m][p] = sum_k a[m][k] * x[b][k][p] (+ addend[b][m][p], may be NULL),   fp32 accumulation, one rounding.
- * a = W [O][I] for the forward pass (m = o, k = i), a = W^T [I][O] for the data gradient.  Replaces the
- * F.conv2d(x, w) of nn.Conv2d(.., 1) (layers.py:95-99,158-206) and its input gradient; the skip additions of
- * the FNO block (sfnonet.py:219-246) ride in `addend`.  K and P must be multiples of 8. */
-int mk_conv1x1_fwd(const void* a, const void* x, const void* addend, void* y, int batch, int M, int K,
-                   long long P, void* stream);
-
 /* Pixel-column engine (csrc/pce.hip): the same 1x1 convolutions as one persistent kernel per GEMM with the
  * pointwise passes of layers.py:86-216 / sfnonet.py:239-267 folded into the epilogue:
  *   acc[b][m][p] = sum_k A[m][k] * x[b][k][p] (+ bias[m]);   aux_out <- acc (bf16, optional: the pre-activation kept for

@@ -64,8 +64,6 @@ SIGNATURES = {
     "mk_wmse_fwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_wmse_bwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_conv1x1_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
-    "mk_conv1x1_wgrad_os": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
-    "mk_conv1x1_fwd": (_c_int, [_vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_pce_image_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "mk_pce_pack": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     "mk_pce_gemm": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),

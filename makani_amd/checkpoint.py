@@ -51,6 +51,8 @@ def collect_flexible_state(model):
 def save_flexible_checkpoint(checkpoint_path, model, iters=0, epoch=0, optimizer=None, scheduler=None, params=None):
     """Write ``checkpoint_path.format(mp_rank=0)`` from world rank 0; every rank of the model-parallel group must call."""
     state = collect_flexible_state(model)
+    if params is not None and not isinstance(params, (dict, list, str, int, float)):
+        params = params.to_dict() if hasattr(params, "to_dict") else dict(vars(params))   # plain data: loadable with weights_only=True
     store = {"iters": iters, "epoch": epoch, "model_state": state, "params": params}
     if optimizer is not None:
         store["optimizer_state_dict"] = optimizer.state_dict()
@@ -62,12 +64,17 @@ def save_flexible_checkpoint(checkpoint_path, model, iters=0, epoch=0, optimizer
         dist.barrier(group=comm.get_group("model"))
 
 
-def restore_flexible_checkpoint(checkpoint_path, model, scheduler=None, load_optimizer=False, load_scheduler=False, logger=None):
+def restore_flexible_checkpoint(checkpoint_path, model, scheduler=None, load_optimizer=False, load_scheduler=False, logger=None,
+                                trusted_pickle=False):
     """Load ``checkpoint_path.format(mp_rank=0)`` into ``model`` under the CURRENT model-parallel layout.  Returns the
-    ``(iters, epoch)`` stored in the file.  Parameters missing from the file are left alone (and reported)."""
+    ``(iters, epoch)`` stored in the file.  Parameters missing from the file are left alone (and reported).
+
+    The file is read with ``weights_only=True`` (tensors, numbers, strings, dicts, lists: everything this function uses);
+    a file whose ``params`` entry holds pickled classes is refused unless the caller vouches for it with
+    ``trusted_pickle=True`` (the reference's ``torch.load`` default, ``trainer.py:1062``, which executes what it loads)."""
     if load_optimizer:
         raise NotImplementedError("Error, restoring optimizer not supported for flexible checkpoint format yet")
-    checkpoint = torch.load(checkpoint_path.format(mp_rank=0), map_location="cpu", weights_only=False)
+    checkpoint = torch.load(checkpoint_path.format(mp_rank=0), map_location="cpu", weights_only=not trusted_pickle)
     state = checkpoint["model_state"]
     with torch.no_grad():
         for k, v in model.named_parameters():

@@ -1,8 +1,7 @@
-// bf16 MFMA kernels for the 1x1 convolutions of the FNO block / encoder / decoder on NCHW fields
+// bf16 MFMA weight-gradient kernels for the 1x1 convolutions of the FNO block / encoder / decoder on NCHW fields
 // viewed as [C][P = H*W] (the pointwise stack between the spectral ops).
 //
 // mk_conv1x1_wgrad:  gW[o][i] += sum_p gY[o][p] * X[i][p]    (contraction over the ~1e5..1e6 pixels)
-// mk_conv1x1_fwd:    Y[m][p] = sum_k A[m][k] * X[k][p] (+ addend)   (forward / data gradient; further down)
 //
 // Both operands are contiguous along the contraction index p, which is exactly the fragment shape of
 // v_mfma_f32_32x32x16_bf16 (lane (r, h) holds 8 consecutive k of row r): tiles are staged with plain
@@ -288,177 +287,6 @@ __global__ __launch_bounds__(WT8) void conv1x1_wgrad_big_kernel(WgradParams p) {
         }
 }
 
-// ---------------------------------------------------------------------------
-// mk_conv1x1_fwd:  Y[b][m][p] = sum_k A[m][k] * X[b][k][p] (+ addend[b][m][p])
-// ---------------------------------------------------------------------------
-// The forward (A = W) and data-gradient (A = W^T) GEMMs of a 1x1 convolution on NCHW fields.  X is k-major
-// (pixels contiguous), which is the wrong way round for the MFMA operand registers (8 consecutive k per
-// lane): the X tile is staged into LDS as it lies in memory, [64 k][128 p], and the fragments are fetched
-// with ds_read_b64_tr_b16, the hardware transposing read (checked in tools/ub/tr_read_ub.hip).  Row pitch
-// 320 B puts the 4 rows x 64 B a 32-lane half touches on 64 distinct banks.  Pixels are de-interleaved
-// while staging (even pixels -> accumulator 0, odd -> accumulator 1) so a lane ends up owning adjacent
-// pixel pairs and the epilogue writes packed bf16x2, one full 128-byte line per row and wave.
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-
-constexpr int NTM = 128, NTN = 128, NTK = 64;
-constexpr int NAP = NTK * 2 + 16;             // A image pitch (bytes): 144
-constexpr int NBP = NTN * 2 + 64;             // B image pitch (bytes): 320
-constexpr int NA_BYTES = NTM * NAP;           // 18,432
-constexpr int NB_BYTES = NTK * NBP;           // 20,480
-constexpr int NSTAGE = NA_BYTES + NB_BYTES;   // 38,912 -> two stages, two workgroups per CU
-
-struct NnParams {
-    const __hip_bfloat16* a;     // [M][K]
-    const __hip_bfloat16* x;     // [B][K][P]
-    const __hip_bfloat16* add;   // [B][M][P] or null
-    __hip_bfloat16* y;           // [B][M][P]
-    int M, K, B, nblk_m;
-    long long P, nblk_n;         // pixel blocks per batch item
-};
-
-__device__ __forceinline__ void nn_load_a(const NnParams& p, int m0, int k0, uint4 (&r)[4], int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int v = tid + i * WT, row = v >> 3, c = v & 7;
-        const int m = m0 + row, k = k0 + c * 8;
-        r[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (m < p.M && k < p.K) r[i] = *reinterpret_cast<const uint4*>(p.a + (long long)m * p.K + k);
-    }
-}
-__device__ __forceinline__ void nn_store_a(char* img, const uint4 (&r)[4], int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int v = tid + i * WT, row = v >> 3, c = v & 7;
-        *reinterpret_cast<uint4*>(img + row * NAP + c * 16) = r[i];
-    }
-}
-__device__ __forceinline__ void nn_load_b(const NnParams& p, const __hip_bfloat16* xb, long long n0, int k0, uint4 (&r)[4],
-                                          int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int v = tid + i * WT, row = v >> 4, c = v & 15;
-        const int k = k0 + row;
-        const long long n = n0 + c * 8;
-        r[i] = make_uint4(0u, 0u, 0u, 0u);
-        if (k < p.K && n < p.P) r[i] = *reinterpret_cast<const uint4*>(xb + (long long)k * p.P + n);
-    }
-}
-// 8 consecutive pixels -> 4 even (accumulator 0) + 4 odd (accumulator 1); image column of pixel pair j of the
-// 64-pixel group g: even g*64 + j, odd g*64 + 32 + j
-__device__ __forceinline__ void nn_store_b(char* img, const uint4 (&r)[4], int tid) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int v = tid + i * WT, row = v >> 4, c = v & 15;
-        uint2 ev, od;
-        ev.x = __builtin_amdgcn_perm(r[i].y, r[i].x, 0x05040100u);
-        od.x = __builtin_amdgcn_perm(r[i].y, r[i].x, 0x07060302u);
-        ev.y = __builtin_amdgcn_perm(r[i].w, r[i].z, 0x05040100u);
-        od.y = __builtin_amdgcn_perm(r[i].w, r[i].z, 0x07060302u);
-        char* dst = img + row * NBP + ((c >> 3) * 64 + (c & 7) * 4) * 2;
-        *reinterpret_cast<uint2*>(dst) = ev;
-        *reinterpret_cast<uint2*>(dst + 64) = od;
-    }
-}
-
-__global__ __launch_bounds__(WT, 2) void conv1x1_fwd_kernel(NnParams p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
-    // block -> (pixel block, m block): the m blocks of one pixel block share blockIdx % 8 (one XCD's L2)
-    const long long bid = blockIdx.x;
-    const int xcd = (int)(bid & 7);
-    const long long seq = bid >> 3;
-    const long long nb_lin = (seq / p.nblk_m) * 8 + xcd;
-    const int mb = (int)(seq % p.nblk_m);
-    if (nb_lin >= p.nblk_n * p.B) return;
-    const int b = (int)(nb_lin / p.nblk_n);
-    const long long n0 = (nb_lin % p.nblk_n) * NTN;
-    const int m0 = mb * NTM;
-    const __hip_bfloat16* xb = p.x + (long long)b * p.K * p.P;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
-
-    const int fr = lane & 31, fh = lane >> 5;
-    // per-lane offsets: A fragment rows (b128), transposed B reads (b64): row 8*(lane>>5) + ((lane&15)>>2),
-    // column 16*((lane>>4)&1) + 4*(lane&3) inside the 32-column accumulator block
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-        a_off[a] = (wr * 64 + a * 32 + fr) * NAP + fh * 16;
-        b_off[a] = NA_BYTES + (8 * fh + ((lane & 15) >> 2)) * NBP + (wc * 64 + a * 32 + 16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-    }
-
-    uint4 ra[4], rb[4];
-    const int nk = (p.K + NTK - 1) / NTK;
-    nn_load_a(p, m0, 0, ra, tid);
-    nn_load_b(p, xb, n0, 0, rb, tid);
-    nn_store_a(lds, ra, tid);
-    nn_store_b(lds + NA_BYTES, rb, tid);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const char* cur = lds + (kt & 1) * NSTAGE;
-        char* nxt = lds + ((kt & 1) ^ 1) * NSTAGE;
-        if (kt + 1 < nk) {
-            nn_load_a(p, m0, (kt + 1) * NTK, ra, tid);
-            nn_load_b(p, xb, n0, (kt + 1) * NTK, rb, tid);
-        }
-#pragma unroll
-        for (int ks = 0; ks < NTK / 16; ++ks) {
-            bf16x8 af[2], bf[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) af[a] = *reinterpret_cast<const bf16x8*>(cur + a_off[a] + ks * 32);
-#pragma unroll
-            for (int c = 0; c < 2; ++c) {
-                const char* q = cur + b_off[c] + ks * 16 * NBP;
-                const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(q));
-                const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-                    (s16x4 __attribute__((address_space(3)))*)(__attribute__((address_space(3))) char*)(q + 4 * NBP));
-                const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-                bf[c] = __builtin_bit_cast(bf16x8, v);
-            }
-#pragma unroll
-            for (int a = 0; a < 2; ++a)
-#pragma unroll
-                for (int c = 0; c < 2; ++c)
-                    acc[a][c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[c], acc[a][c], 0, 0, 0);
-        }
-        if (kt + 1 < nk) {
-            nn_store_a(nxt, ra, tid);
-            nn_store_b(nxt + NA_BYTES, rb, tid);
-        }
-        __syncthreads();
-    }
-    // C/D map: col = lane & 31 (pixel pair), row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const long long n = n0 + wc * 64 + 2 * fr;
-    if (n < p.P) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (m < p.M) {
-                    const long long o = ((long long)b * p.M + m) * p.P + n;
-                    float v0 = acc[a][0][r], v1 = acc[a][1][r];
-                    if (p.add) {
-                        const __hip_bfloat162 ad = *reinterpret_cast<const __hip_bfloat162*>(p.add + o);
-                        v0 += __bfloat162float(ad.x);
-                        v1 += __bfloat162float(ad.y);
-                    }
-                    *reinterpret_cast<__hip_bfloat162*>(p.y + o) = __float22bfloat162_rn(make_float2(v0, v1));
-                }
-            }
-    }
-}
-
 }  // namespace
 
 extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
@@ -590,38 +418,6 @@ extern "C" int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int ba
             default: hipLaunchKernelGGL((conv1x1_wgrad_kernel<2, 64, 1>), g, b, lds, (hipStream_t)stream, p); break;
         }
     }
-    MK_LAUNCH_CHECK();
-    return 0;
-}
-
-extern "C" int mk_conv1x1_fwd(const void* a, const void* x, const void* addend, void* y, int batch, int M, int K,
-                              long long P, void* stream) {
-    MK_REQUIRE(a && x && y, "null pointer");
-    MK_REQUIRE(batch > 0 && M > 0 && K > 0 && P > 0, "bad sizes");
-    MK_REQUIRE((P % 8) == 0 && (K % 8) == 0, "K and P = H*W must be multiples of 8 (16-byte row alignment)");
-    MK_REQUIRE((((uintptr_t)a | (uintptr_t)x | (uintptr_t)y | (uintptr_t)addend) & 15) == 0,
-               "a, x, y and addend must be 16-byte aligned (the tiles are read as uint4)");
-    NnParams p;
-    p.a = (const __hip_bfloat16*)a;
-    p.x = (const __hip_bfloat16*)x;
-    p.add = (const __hip_bfloat16*)addend;
-    p.y = (__hip_bfloat16*)y;
-    p.M = M;
-    p.K = K;
-    p.B = batch;
-    p.P = P;
-    p.nblk_m = mk::ceil_div(M, NTM);
-    p.nblk_n = (P + NTN - 1) / NTN;
-    const long long nb = p.nblk_n * batch;
-    const long long grid = ((nb + 7) / 8) * 8 * p.nblk_m;
-    MK_REQUIRE(grid < 2147483647LL, "grid too large");
-    static const bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  2 * NSTAGE);
-        return true;
-    }();
-    (void)once;
-    hipLaunchKernelGGL(conv1x1_fwd_kernel, dim3((unsigned)grid), dim3(WT), 2 * NSTAGE, (hipStream_t)stream, p);
     MK_LAUNCH_CHECK();
     return 0;
 }

@@ -424,28 +424,10 @@ __global__ __launch_bounds__(STHREADS, PERSIST ? 3 : 5) void irfft_split_kernel(
   }
 }
 
-// Inverse kernel: MK_FFT_WGS = n > 0 launches n persistent workgroups per CU (PERSIST = 1); 0 (default) one workgroup per tile
-// (PERSIST = 0).  Measured on one box, alternating: bf16 rows out at 721 x 1440 0.595 -> 0.505 ms, at 240 x 480 0.094 -> 0.074 ms
-// (2 persistent workgroups -> one per tile), the step 44.31 / 44.44 -> 43.80 / 43.77 ms: three workgroups per CU covering
-// each other beat two with a register prefetch, as in the forward kernel.
-static inline int fft_wgs_per_cu() {
-    static const int per_cu = [] {
-        const char* e = getenv("MK_FFT_WGS");
-        return e ? atoi(e) : 0;
-    }();
-    return per_cu;
-}
-static inline unsigned split_grid(long long tiles) {
-    const int per_cu = fft_wgs_per_cu();
-    static const int cus = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 256;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) return 256;
-        return v;
-    }();
-    const long long cap = (long long)per_cu * cus, t16 = (tiles + 15) / 16 * 16;
-    return (unsigned)((per_cu > 0 && t16 > cap) ? cap : t16);
-}
+// Inverse kernel: one workgroup per tile (three per CU covering each other, as in the forward kernel).  Two persistent
+// workgroups per CU with the next tile's mode gather prefetched in registers measured 15-21 % slower (0.595 vs 0.505 ms at
+// 721 x 1440, 0.094 vs 0.074 ms at 240 x 480) and were removed; PERSIST = 1 survives only as the loop of the WIDE variant.
+static inline unsigned split_grid(long long tiles) { return (unsigned)((tiles + 15) / 16 * 16); }
 
 // ablation switches for the forward kernel (MK_FFT_EXP): 1 no row loads, 2 no FFT passes, 4 no mode stores,
 // 8 stop after the passes -- wrong results, timing experiments only
@@ -481,14 +463,13 @@ int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, i
     // 32-bit mode offsets inside a tile's buffer descriptor: (240 modes + one row of channels) * 8 bytes must stay below 2^31
     const long long bcx = g_xl.Cp ? (long long)g_xl.Bn * g_xl.Cp : (long long)bc;
     const bool wide = ((long long)SH * g_xl.sm + 1) * bcx * 8 >= (1LL << 31);
-    const bool persist = wide || fft_wgs_per_cu() > 0;      // MK_FFT_WGS=0: the one-tile-per-workgroup variant
 #define MK_IRFFT_LAUNCH(T, W, PS)                                                                                      \
     hipLaunchKernelGGL((irfft_split_kernel<S, T, W, PS>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,        \
                        (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl)
     if (x_dtype == 0) {
-        if (wide) MK_IRFFT_LAUNCH(float, true, 1); else if (persist) MK_IRFFT_LAUNCH(float, false, 1); else MK_IRFFT_LAUNCH(float, false, 0);
+        if (wide) MK_IRFFT_LAUNCH(float, true, 1); else MK_IRFFT_LAUNCH(float, false, 0);
     } else {
-        if (wide) MK_IRFFT_LAUNCH(__hip_bfloat16, true, 1); else if (persist) MK_IRFFT_LAUNCH(__hip_bfloat16, false, 1); else MK_IRFFT_LAUNCH(__hip_bfloat16, false, 0);
+        if (wide) MK_IRFFT_LAUNCH(__hip_bfloat16, true, 1); else MK_IRFFT_LAUNCH(__hip_bfloat16, false, 0);
     }
 #undef MK_IRFFT_LAUNCH
     return 0;

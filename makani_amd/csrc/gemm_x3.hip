@@ -54,7 +54,6 @@ constexpr int XPITCH = 208;                   // LDS row pitch: 192 data + 16 pa
 constexpr int XROWB = 192;                    // bytes of one row per k-step: [3][32] bf16
 constexpr int XIMG = XM * XPITCH + 128;       // one operand image (+128: offset of the odd half, see pair_off)
 constexpr int X3_LDS = 2 * XIMG;              // 53,504 B
-constexpr int XCHUNK = XM * XROWB;            // 24,576 B: one pre-split [128 rows][3][32] block in HBM
 
 // LDS row offsets.  plain: row r at r * pitch.  pair: rows 2t, 2t+1 are written by one thread (lane t), so
 // they live 64 rows (+128 B) apart -- 8 consecutive lanes then hit 8 consecutive rows (conflict-free
@@ -115,33 +114,9 @@ __device__ __forceinline__ float2 x3_load8(__amdgpu_buffer_rsrc_t rs, unsigned o
 
 __device__ __forceinline__ int quad_row(int lane);
 
-// Pre-split constant operand: k-step kt of this tile is the contiguous XCHUNK block base + kt * XCHUNK.
-// All 128 rows are copied unconditionally: skipping the dead rows of ragged tiles behind (wave-uniform)
-// branches measured 10-15 % slower than the straight copy.
-struct PresplitStager {
-    const char* base;
-    static constexpr int TILE_BYTES = XCHUNK;
-    typedef u32x4 Regs[6];
-    static __device__ __forceinline__ int row_off(int r) { return plain_off(r); }
-    __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
-        const char* p = base + (long long)kt * XCHUNK + tid * 16;
-#pragma unroll
-        for (int q = 0; q < 6; ++q) r[q] = *reinterpret_cast<const u32x4*>(p + q * XT * 16);
-    }
-    __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
-#pragma unroll
-        for (int q = 0; q < 6; ++q) {
-            const int g = tid + q * XT;
-            const int row = g / 12, c = g - row * 12;
-            *reinterpret_cast<u32x4*>(img + row * XPITCH + c * 16) = r[q];
-        }
-    }
-};
-
-// The same constant operand kept as fp32 tiles ([128 rows][32 k] floats = 16 KB per k-step instead of 24 KB) and split
-// while staging: a third less panel traffic through the load path for 88 more VALU operations per thread and k-step
-// (the default; MK_X3_TABLE=presplit selects the image above).  2 % faster than the pre-split image on all four production
-// launches in isolation and 0 - 0.2 ms per step, with two thirds of the table bytes.
+// The constant operand (Legendre table) as fp32 tiles ([128 rows][32 k] floats = 16 KB per k-step), split into the bf16x3
+// pieces while staging.  (A pre-split bf16x3 image -- 24 KB per k-step copied straight into LDS -- was built and measured
+// 2 % slower in isolation and 0 - 0.2 ms per step slower, with one half more table bytes; removed in round 3.)
 struct F32TileStager {
     const char* base;
     typedef float4 Regs[4];
@@ -181,12 +156,15 @@ struct TransStager {
     __device__ __forceinline__ void gload(int kt, Regs& r, int tid) const {
         const int w = tid >> 6, c = (tid & 63) * 2;
         const int k0 = kt * XK + w * 8;
-        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base);
+        // the descriptor is rebased to the first row of the k-step (a 64-bit pointer), so the 32-bit offsets only span the
+        // 32 rows of the step: operands of any size (k-major Fourier rows of a large batch pass 2^31 bytes: 721 x 241 x 384
+        // channels x 8 B = 534 MB per sample) stay addressable; the launchers require 32 * ldk * 4 < 2^31
+        const __amdgpu_buffer_rsrc_t rs = x3_rsrc(base + (long long)kt * XK * ldk);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int k = k0 + i;
             const bool ok = k >= k_lo && k < k_hi && c < cvalid;
-            r[i] = x3_load8(rs, ok ? (unsigned)(((long long)k * ldk + c) * 4) : X3_OOB);
+            r[i] = x3_load8(rs, ok ? (unsigned)(((long long)(w * 8 + i) * ldk + c) * 4) : X3_OOB);
         }
     }
     __device__ __forceinline__ void sstore(const Regs& r, char* img, int tid) const {
@@ -635,8 +613,8 @@ __global__ __launch_bounds__(XT, 3) void dhconv_wgrad_x3_kernel(DhX3Params p) {
 }
 
 // table [M][L][KP] fp32 -> pre-split image.  One thread per (block, row, kk).
-__global__ void legendre_x3_split_kernel(const float* __restrict__ tab, uint16_t* __restrict__ out, int K, int KP, int L,
-                                         int M, int RT, int KC, int inverse, int f32tiles, long long total) {
+__global__ void legendre_x3_split_kernel(const float* __restrict__ tab, void* __restrict__ out, int K, int KP, int L,
+                                         int M, int RT, int KC, int inverse, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int kk = (int)(idx & 31);
@@ -656,23 +634,7 @@ __global__ void legendre_x3_split_kernel(const float* __restrict__ tab, uint16_t
     }
     float v = 0.f;
     if (l < L && k < K) v = tab[((long long)m * L + l) * KP + k];
-    if (f32tiles) {
-        reinterpret_cast<float*>(out)[idx] = v;   // [block][128 rows][32 k] fp32
-        return;
-    }
-    const Split3 s = split3(v);
-    uint16_t* o = out + (idx >> 5) * 96 + kk;
-    o[0] = (uint16_t)(s.h >> 16);
-    o[32] = (uint16_t)(s.m >> 16);
-    o[64] = (uint16_t)(s.l >> 16);
-}
-
-static int x3_f32tiles() {
-    // fp32 tiles split while staging by default (MK_X3_TABLE=presplit: the bf16x3 image): in the step 45.07 / 45.08 ->
-    // 44.82 / 44.88 ms on one box, within noise on another (alternating runs), and two thirds of the image bytes; the results are bit-identical
-    // (the same exact split, done earlier or later)
-    static const int v = [] { const char* e = getenv("MK_X3_TABLE"); return (e && e[0] == 'p') ? 0 : 1; }();
-    return v;
+    reinterpret_cast<float*>(out)[idx] = v;   // [block][128 rows][32 k] fp32
 }
 
 static void x3_layout(int nlat, int lmax, int inverse, int* RT, int* KC) {
@@ -691,7 +653,7 @@ extern "C" long long mk_legendre_x3_bytes(int nlat, int lmax, int mmax, int inve
     if (nlat <= 0 || lmax <= 0 || mmax <= 0) return 0;
     int RT, KC;
     x3_layout(nlat, lmax, inverse, &RT, &KC);
-    return (long long)mmax * RT * KC * (x3_f32tiles() ? F32TileStager::TILE_BYTES : XCHUNK);
+    return (long long)mmax * RT * KC * F32TileStager::TILE_BYTES;
 }
 
 extern "C" int mk_legendre_x3_split(const float* tab, void* out, int nlat, int lmax, int mmax, int inverse, void* stream) {
@@ -703,7 +665,7 @@ extern "C" int mk_legendre_x3_split(const float* tab, void* out, int nlat, int l
     const long long nblk = (total + 255) / 256;
     MK_REQUIRE(nblk < 2147483647LL, "grid too large");
     hipLaunchKernelGGL(legendre_x3_split_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, tab,
-                       (uint16_t*)out, nlat, mk_legendre_kpad(nlat), lmax, mmax, RT, KC, inverse, x3_f32tiles(), total);
+                       out, nlat, mk_legendre_kpad(nlat), lmax, mmax, RT, KC, inverse, total);
     MK_LAUNCH_CHECK();
     return 0;
 }
@@ -725,14 +687,11 @@ static int legendre_x3_launch(bool fwd, const float* src, const void* tab, float
     p.exp = x3_exp();
     const long long nblk = grid_blocks(mmax_loc, p.RT, p.tiles_n);
     if (nblk >= 2147483647LL) return -1;
+    // TransStager: 32-bit byte offsets inside one 32-row k-step of the data operand (row stride Mloc * N2 floats at most)
+    if (33LL * p.Mloc * p.N2 * 4 >= (1LL << 31)) return -2;
     const dim3 grid((unsigned)nblk), blk(XT);
-    if (x3_f32tiles()) {
-        if (fwd) hipLaunchKernelGGL(legendre_fwd_x3_kernel<F32TileStager>, grid, blk, X3_LDS, st, p);
-        else hipLaunchKernelGGL(legendre_inv_x3_kernel<F32TileStager>, grid, blk, X3_LDS, st, p);
-    } else {
-        if (fwd) hipLaunchKernelGGL(legendre_fwd_x3_kernel<PresplitStager>, grid, blk, X3_LDS, st, p);
-        else hipLaunchKernelGGL(legendre_inv_x3_kernel<PresplitStager>, grid, blk, X3_LDS, st, p);
-    }
+    if (fwd) hipLaunchKernelGGL(legendre_fwd_x3_kernel<F32TileStager>, grid, blk, X3_LDS, st, p);
+    else hipLaunchKernelGGL(legendre_inv_x3_kernel<F32TileStager>, grid, blk, X3_LDS, st, p);
     return 0;
 }
 
@@ -743,7 +702,7 @@ extern "C" int mk_legendre_fwd_x3_ex(const float* xf, const void* tab_x3, float*
     MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
     MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
     MK_REQUIRE(legendre_x3_launch(true, xf, tab_x3, c, bc, nlat, lmax, mmax_loc, m_off, xf_layout, (hipStream_t)stream) == 0,
-               "grid too large");
+               "operand too large: grid over 2^31 blocks, or 33 * mmax_loc * 2 * bc * 4 bytes (one k-step of the data operand) over 2^31");
     MK_LAUNCH_CHECK();
     return 0;
 }
@@ -760,7 +719,7 @@ extern "C" int mk_legendre_inv_x3_ex(const float* c, const void* tab_x3, float* 
     MK_REQUIRE(m_off >= 0 && m_off + mmax_loc <= mmax_glob, "mode shard out of range");
     MK_REQUIRE(xf_layout == 0 || xf_layout == 1, "xf_layout must be 0 ([M][K][BC]) or 1 ([K][M][BC])");
     MK_REQUIRE(legendre_x3_launch(false, c, tab_x3, xf, bc, nlat, lmax, mmax_loc, m_off, xf_layout, (hipStream_t)stream) == 0,
-               "grid too large");
+               "operand too large: grid over 2^31 blocks, or 33 * mmax_loc * 2 * bc * 4 bytes (one k-step of the data operand) over 2^31");
     MK_LAUNCH_CHECK();
     return 0;
 }

@@ -24,6 +24,7 @@
 // resident X fragments.
 #include "common.h"
 #include "../../include/makani_amd.h"
+#include "pce_common.h"
 
 #include <hip/hip_bf16.h>
 #include <cstdint>
@@ -32,12 +33,7 @@
 #include <utility>
 
 namespace {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef short s16x8 __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+using namespace pce;
 
 constexpr int PT = 512;         // threads: 8 waves = 4 pixel groups x 2 row halves
 constexpr int PN = 128;         // pixels per tile
@@ -45,9 +41,9 @@ constexpr int XROW = PN * 2;    // bytes of one k row of the X tile in LDS
 constexpr int PCE_KPHASE = 384; // k rows resident per phase
 
 #ifdef MK_PCE_ABLATE     // profiling build only (tools/pce_ablate.py): run-time ablation checks cost the hot loops
-#define WS_EXP(bit) (p.exp & (bit))
+#define PCE_EXP(bit) (p.exp & (bit))
 #else
-#define WS_EXP(bit) false
+#define PCE_EXP(bit) false
 #endif
 
 struct PceParams {
@@ -77,108 +73,6 @@ struct PceParams {
     int Mb;                        // rows of one batch item (batch stride of y / addend / aux / rowstats); = M on entry
 };
 
-// ---- GELU (exact erf form, makani uses nn.GELU()) on the VALU budget of an epilogue --------------------------
-// Phi(x) through erfc(|x|/sqrt2) with the Abramowitz-Stegun 7.1.26 rational-exponential form (|error| < 1.5e-7
-// absolute on erf): 2 transcendentals + ~12 FMAs instead of ~30 instructions of erff().  The results are rounded
-// to bf16 (2^-9 relative) right after.
-struct PhiPair {
-    float Phi, phi;   // standard normal CDF and PDF at x
-};
-__device__ __forceinline__ PhiPair normal_cdf_pdf(float x) {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float q = fmaf(1.061405429f, t, -1.453152027f);
-    q = fmaf(q, t, 1.421413741f);
-    q = fmaf(q, t, -0.284496736f);
-    q = fmaf(q, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);   // exp(-x^2/2)
-    const float half_erfc = 0.5f * q * t * e;                               // 0.5 erfc(|x|/sqrt2) = Phi(-|x|)
-    PhiPair r;
-    r.Phi = x < 0.f ? half_erfc : 1.0f - half_erfc;
-    r.phi = 0.3989422804014327f * e;
-    return r;
-}
-__device__ __forceinline__ float gelu_f(float x) { return x * normal_cdf_pdf(x).Phi; }
-__device__ __forceinline__ float gelu_grad_f(float x) {
-    const PhiPair c = normal_cdf_pdf(x);
-    return fmaf(x, c.phi, c.Phi);
-}
-
-__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
-__device__ __forceinline__ unsigned short f32_to_bf16_bits(float v) {
-    const __hip_bfloat16 h = __float2bfloat16(v);
-    return *reinterpret_cast<const unsigned short*>(&h);
-}
-
-// ---- LDS-DMA and hand-scheduled LDS reads ----------------------------------------------------------------------
-// The compiler treats an outstanding LDS-DMA as a pending write to ALL of LDS and drains vmcnt(0) in front of the
-// next LDS read it can see; the weight-fragment reads therefore go through inline asm with hand-counted waits.
-__device__ __forceinline__ void dma16(const void* gptr, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
-}
-template <int OFF>
-__device__ __forceinline__ bf16x8 lds_read_frag(uint32_t addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return __builtin_bit_cast(bf16x8, v);
-}
-template <int OFF>
-__device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
-    u32x4 v;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-template <int OFF>
-__device__ __forceinline__ void lds_write_b128(uint32_t addr, u32x4 v) {
-    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-// low / high 16 bits of a VGPR
-template <int OFF>
-__device__ __forceinline__ void lds_write_b16_lo(uint32_t addr, uint32_t v) {
-    asm volatile("ds_write_b16 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-template <int OFF>
-__device__ __forceinline__ void lds_write_b16_hi(uint32_t addr, uint32_t v) {
-    asm volatile("ds_write_b16_d16_hi %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-template <int OFF>
-__device__ __forceinline__ u32x2 lds_read_tr16(uint32_t addr) {
-    u32x2 v;
-    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
-    return v;
-}
-__device__ __forceinline__ void lds_write_b32(uint32_t addr, float v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(addr), "v"(v) : "memory");
-}
-__device__ __forceinline__ float lds_read_b32(uint32_t addr) {
-    float v;
-    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
-    const bf16x2 t = {(__bf16)lo, (__bf16)hi};
-    return __builtin_bit_cast(uint32_t, t);
-}
-template <int N>
-__device__ __forceinline__ void wait_lgkm() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-__device__ __forceinline__ void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-// raw s_barrier (no vmcnt(0) fence: LDS-DMA may stay in flight across it) between compiler-level memory fences
-__device__ __forceinline__ void block_sync() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-}
-__device__ __forceinline__ void keep_alive(const f32x16& v) { asm volatile("" ::"v"(v)); }
-__device__ __forceinline__ uint32_t lds_addr(const char* p) {
-    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
-}
-
 // One weight slot = all 2*TH row tiles of one k16 step; this wave (row half mh) multiplies TH of them, in groups of
 // NF fragments: NF reads in flight, each MFMA issued as soon as its fragment has arrived.
 template <int NF, int T0, int I>
@@ -194,8 +88,6 @@ struct FragLoop {
         if constexpr (I + 1 < NF) FragLoop<NF, T0, I + 1>::template mfma<TH>(af, b, acc);
     }
 };
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // ---- epilogue of one pass -----------------------------------------------------------------------------------------
 // The MFMAs run "transposed" (A = pixel fragment, B = weight fragment), so an accumulator holds its 32 output rows m on
@@ -211,16 +103,6 @@ struct EpiAddr {
     uint32_t st_lin;                // this lane's 16-byte piece of the linear view (second piece: + 1024)
     int row_lin, px_lin;            // linear piece q: row = 16 q + row_lin, pixel offset px_lin
 };
-
-template <int OFF>
-__device__ __forceinline__ void lds_write_b64(uint32_t addr, u32x2 v) {
-    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ u32x2 lds_read_b64(uint32_t addr) {
-    u32x2 v;
-    asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr) : "memory");
-    return v;
-}
 
 // HAS_IN is a template parameter and the bias load is unconditional on purpose: the compiler's waitcnt pass is path
 // insensitive, and a VGPR load that sits behind a run-time `if` stays "possibly pending" for it after the join -- it then
@@ -500,7 +382,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     // The work of a workgroup is a sequence of ITEMS (tile, pass): all passes of a tile back to back, then the next tile.
     auto issue_next_group = [&](bool item_after_exists) {
         if (si_next && !item_after_exists) return;
-        if (!WS_EXP(4)) issue_group(spass * ngroup_tile + si, gi % NBUF);
+        if (!PCE_EXP(4)) issue_group(spass * ngroup_tile + si, gi % NBUF);
         ++gi;
         if (++si == ngroup_tile) {
             si = 0;
@@ -620,7 +502,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                 const int ch = 4 * pg + 2 * ((l >> 4) & 1) + ((l & 3) >> 1);
                 const uint32_t xfrag_lane = lds_addr(XS) + region * REG_BYTES + (8 * (l >> 5) + rowq) * XROW +
                                             ((ch + 4 * rowq) & 15) * 16 + (l & 1) * 8;
-                if (!WS_EXP(16)) {
+                if (!PCE_EXP(16)) {
                     u32x2 lo[KSP], hi[KSP];
                     [&]<int... SS>(std::integer_sequence<int, SS...>) {
                         ((lo[SS] = lds_read_tr16<SS * 16 * XROW>(xfrag_lane), hi[SS] = lds_read_tr16<SS * 16 * XROW + 4 * XROW>(xfrag_lane)), ...);
@@ -637,7 +519,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
             // fetched into this region while the phase computes: the phase NREG ahead (of this item, or of the next one)
             XTarget xt;
             xt.active = false;
-            if (!WS_EXP(8)) {
+            if (!PCE_EXP(8)) {
                 if (phase + NREG < NPH) xt = x_target(tile, phase + NREG, region);
                 else if (item_after) xt = x_target(next_tile, phase + NREG - NPH, region);
             }
@@ -651,11 +533,11 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
                     else if (cx == 1) wait_vm<1>();
                     else wait_vm0();
                 }
-                if (!WS_EXP(32)) block_sync();                  // group g + 1 visible; nobody reads group g - 1 any more
+                if (!PCE_EXP(32)) block_sync();                  // group g + 1 visible; nobody reads group g - 1 any more
                 stamp();   // 4 + 2 gq
                 issue_next_group(item_after);                   // group g + 2 -> the buffer of group g - 1
                 cx = (gq < XG && xt.active) ? issue_x(xt, gq) : 0;
-                if (!WS_EXP(2)) {
+                if (!PCE_EXP(2)) {
                     const uint32_t a = a_lane + (g % NBUF) * GROUP;
                     FragLoop<TH, 0, 0>::issue(a + SLOT, af1);                       // step 1 of group g
                     wait_lgkm<TH>();                                                // af0 (older) has arrived
@@ -686,7 +568,7 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
         landed = gi;
         cx = 0;
         stamp();
-        if (!WS_EXP(1)) {
+        if (!PCE_EXP(1)) {
             EpiAddr ea;
             const int l = opaque_lane();
             const uint32_t stg = lds_addr(WB) + NBUF * GROUP + wave * 2048;    // wave-private [32 rows][32 px] bf16 tile
@@ -729,371 +611,6 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
     wait_vm0();
 }
 
-// =====================================================================================================================
-// Weight-stationary variant: 64 < K <= 384, M > 128.
-//
-// What bounds the streaming kernel above is the weight stream itself: per 128-pixel tile a CU pulls 288 KB of weight
-// fragments out of L2 through the same in-order vector-memory path that carries the 96 KB X tile from HBM, with at most
-// ~80 KB in flight (the LDS ring) -- by Little's law that is 15 us per tile whatever the MFMAs do.  Here the weights never
-// move: a workgroup of 4 waves (one per SIMD, up to 512 registers each) loads the fragments of 384 output rows x K <= 384
-// ONCE (wave rg keeps rows 96 rg .. 96 rg + 95: 3 row tiles x 24 k16 steps x 4 VGPRs = 288 registers) and then only X
-// flows: 64-pixel tiles through a ring of ten 16 KB LDS regions (one region = one K phase of 128 rows x 64 px), filled
-// by LDS-DMA up to nine regions (144 KB) ahead.  Every wave reads the whole X tile out of LDS (transposing reads, 4 per
-// k16 step feeding 6 MFMAs) -- LDS traffic 43 B/clk of 256.  M = 768 runs as two row halves on different workgroups
-// of the same XCD (w and w + 8 walk the same tile sequence: the second fetch of an X tile finds it in that L2).
-//
-// Pixel order inside a 32-pixel MFMA tile: A-operand row 8 g + 4 h + i carries pixel 16 h + 4 g + i (the transposing
-// read takes any four 8-byte pieces per 16-lane group, so this costs nothing).  An accumulator then holds, for output row
-// m = lane % 32, the 16 CONSECUTIVE pixels 16 h .. 16 h + 15 (h = lane / 32) in its 16 registers: the epilogue packs them
-// and stores 2 x 16 bytes per lane straight to global memory -- no LDS transpose, no waits.
-//
-// The second input of the epilogue (addend / aux_in) comes through the same DMA ring as further regions per tile
-// ([rows][64 px], chunks rotated by row >> 1 so that the per-row ds_read_b128 of a tile spreads over the banks), so the
-// epilogue issues no vector loads at all and the only things in a wave's vmcnt queue are its DMA pieces (a static number
-// per slot) and its output stores.  vmcnt retires in issue order: "slot q has landed" is "all but my PW x (slots issued
-// after q) youngest operations"; stores queued since only make that wait stricter, never wrong.
-//
-// With one wave per SIMD nothing hides a wave's own overhead, so the DMA address arithmetic is incremental (a per-lane
-// pointer that steps by 8 rows) and its pieces are issued one by one in the shadow of the MFMAs of a k16 step.
-// =====================================================================================================================
-constexpr int WS_THREADS = 256;
-constexpr int WS_PN = 64;
-constexpr int WS_ROWS = 384;            // rows of one workgroup (4 waves x 3 row tiles)
-constexpr int WS_LDS = 160 * 1024;
-
-
-template <int KSP, int NPH, bool HAS_IN>
-struct WsGeom {
-    static constexpr int RT = 3, NPT = 2;
-    static constexpr int KS = KSP * NPH;
-    static constexpr int PW = (2 * KSP + 3) / 4;              // 1 KB pieces (8 rows x 64 px) per wave and region
-    static constexpr int REG_BYTES = 4 * PW * 1024;
-    static constexpr int IN_ROWS = REG_BYTES / 128;           // rows of the second input per region
-    static constexpr int NIN = HAS_IN ? (WS_ROWS + IN_ROWS - 1) / IN_ROWS : 0;
-    static constexpr int NSLOT = NPH + NIN;                   // slots per tile: K phases of X, then the second input
-    static constexpr int R = WS_LDS / REG_BYTES > 12 ? 12 : WS_LDS / REG_BYTES;
-    static constexpr int cum(int ph) { return ph * NSLOT / NPH; }       // slots issued by the phases before ph
-    static constexpr int depth() {                            // slots in flight ahead of the one being consumed
-        int d = R;
-        for (int ph = 0; ph < NPH; ++ph) d = d < R + ph - cum(ph + 1) ? d : R + ph - cum(ph + 1);
-        return d;
-    }
-    static constexpr int D = depth();
-    static constexpr int LDS = R * REG_BYTES;
-    static_assert(D >= 2, "ring too small");
-    static_assert(PW * (D + NSLOT) < 64, "vmcnt is a 6-bit counter");
-};
-
-template <int KSP, int NPH, bool HAS_IN>
-__global__ __launch_bounds__(WS_THREADS, 1) void pce_ws_kernel(PceParams p) {
-    using G = WsGeom<KSP, NPH, HAS_IN>;
-    constexpr int RT = G::RT, NPT = G::NPT, KS = G::KS, PW = G::PW, REG_BYTES = G::REG_BYTES, IN_ROWS = G::IN_ROWS;
-    constexpr int NIN = G::NIN, R = G::R, D = G::D, NSLOT = G::NSLOT;
-    extern __shared__ __attribute__((aligned(1024))) char lds[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);        // = row group
-    const int nh = p.npass;
-    const int half = ((int)blockIdx.x >> 3) % nh;
-    const int stream = ((int)blockIdx.x & 7) + 8 * ((int)blockIdx.x / (8 * nh));
-    const int nstreams = (int)gridDim.x / nh;
-    const int tiles_per_b = (int)p.tiles_per_b;
-    const unsigned short* in2 = reinterpret_cast<const unsigned short*>(p.aux_in ? p.aux_in : p.addend);
-    const bool mul_gelu_grad = p.aux_in != nullptr;
-    const long long rowbytes = 2 * p.P;
-    auto opaque_lane = [&]() {
-        int l = lane;
-        asm volatile("" : "+v"(l));
-        return l;
-    };
-
-    // ---- the weights of this wave's 96 rows: resident for the whole launch ----
-    bf16x8 wf[KS][RT];
-    {
-        const char* wsrc = p.wimg + (long long)half * p.img_per_pass + (wave * RT) * 1024 + lane * 16;
-#pragma unroll
-        for (int s = 0; s < KS; ++s)
-#pragma unroll
-            for (int t = 0; t < RT; ++t) wf[s][t] = *reinterpret_cast<const bf16x8*>(wsrc + (s * 12 + t) * 1024);
-    }
-    const int m_first = half * WS_ROWS + wave * 32 * RT;
-    float bias_t[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) bias_t[t] = p.bias[min(m_first + 32 * t + (lane & 31), p.nbias - 1)];
-
-    // ---- DMA issue side.  Slot sequence of a workgroup: (tile, slot 0 .. NSLOT-1), region = running slot index mod R.
-    //      One piece = 8 rows x 64 px; wave w issues pieces w PW .. w PW + PW - 1 of a region, so its rows are
-    //      8 (w PW + j) + (lane >> 3), walked by a per-lane pointer. ----
-    int it_b = 0, it_t = stream;            // tile of the slot being issued: batch item, tile inside it
-    while (it_t >= tiles_per_b && it_b < p.B) {
-        it_t -= tiles_per_b;
-        ++it_b;
-    }
-    int it_slot = 0, it_piece = 0, it_reg = 0;
-    const char* it_ptr = nullptr;           // this lane's source of the next piece (garbage when !it_ok)
-    int it_row = 0;                         // its row: k row (X slots) / row inside the 384-row half (second input)
-    bool it_ok = false;                     // tile inside the launch and this lane's pixels inside the field
-    auto start_slot = [&]() {               // called with it_piece == 0
-        const int l = opaque_lane();
-        const int r8 = l >> 3, cpos = l & 7;
-        const bool x_slot = !HAS_IN || it_slot < NPH;
-        // chunk rotation of the region images (source side: DMA writes lane-linear)
-        const int rot = x_slot ? 4 * ((r8 >> 1) & 1) : ((4 * wave * PW + (r8 >> 1)) & 7);
-        const int c = (cpos - rot) & 7;
-        const long long px = (long long)it_t * WS_PN + 8 * c;
-        it_ok = it_b < p.B && px < p.P;
-        if (x_slot) {
-            it_row = it_slot * 16 * KSP + 8 * wave * PW + r8;
-            it_ptr = reinterpret_cast<const char*>(p.x + ((long long)it_b * p.K + it_row) * p.P + px);
-        } else {
-            it_row = (it_slot - NPH) * IN_ROWS + 8 * wave * PW + r8;
-            it_ptr = reinterpret_cast<const char*>(in2 + ((long long)it_b * p.M + half * WS_ROWS + it_row) * p.P + px);
-        }
-    };
-    auto issue_piece = [&]() {
-        if (it_piece == 0) start_slot();
-        const bool x_slot = !HAS_IN || it_slot < NPH;
-        bool ok = it_ok;
-        const char* src = it_ptr;
-        if (x_slot) {
-            ok = ok && it_row < (it_slot + 1) * 16 * KSP && it_row < p.K;
-        } else {
-            ok = ok && it_row < WS_ROWS && half * WS_ROWS + it_row < p.M;
-            // the rotation of an input row depends on the piece: rows 8 n .. 8 n + 7 -> (4 n + (r8 >> 1)) & 7
-            if (it_piece & 1) {
-                const int l = opaque_lane();
-                const int cpos = l & 7, r8 = l >> 3;
-                const int c0 = (cpos - ((4 * wave * PW + (r8 >> 1)) & 7)) & 7, c1 = (c0 - 4) & 7;
-                src += 16 * (c1 - c0);
-                ok = it_b < p.B && (long long)it_t * WS_PN + 8 * c1 < p.P && it_row < WS_ROWS && half * WS_ROWS + it_row < p.M;
-            }
-        }
-        if (!WS_EXP(8)) dma16(ok ? (const void*)src : (const void*)p.zeros, lds + it_reg * REG_BYTES + (wave * PW + it_piece) * 1024);
-        it_ptr += 8 * rowbytes;
-        it_row += 8;
-        if (++it_piece == PW) {
-            it_piece = 0;
-            if (++it_reg == R) it_reg = 0;
-            if (++it_slot == NSLOT) {
-                it_slot = 0;
-                it_t += nstreams;
-                while (it_t >= tiles_per_b && it_b < p.B) {
-                    it_t -= tiles_per_b;
-                    ++it_b;
-                }
-            }
-        }
-    };
-#pragma unroll 1
-    for (int i = 0; i < D * PW; ++i) issue_piece();
-
-    float rs1[RT], rs2[RT];
-#pragma unroll
-    for (int t = 0; t < RT; ++t) rs1[t] = rs2[t] = 0.f;
-    int rs_b = -1;
-    auto flush_rowstats = [&]() {          // this wave's rows are its own: no cross-wave step
-        if (!p.rowstats || rs_b < 0) return;
-        const int l = opaque_lane();
-#pragma unroll
-        for (int t = 0; t < RT; ++t) {
-            const float a = rs1[t] + __shfl_xor(rs1[t], 32), b2 = rs2[t] + __shfl_xor(rs2[t], 32);
-            const int m = m_first + 32 * t + (l & 31);
-            if (l < 32 && m < p.M) {
-                atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2, (double)a);
-                atomicAdd(p.rowstats + ((long long)rs_b * p.M + m) * 2 + 1, (double)b2);
-            }
-            rs1[t] = rs2[t] = 0.f;
-        }
-    };
-
-    int q_reg = 0;                         // region of the slot being consumed
-    const uint32_t lds0 = lds_addr(lds);
-    int b = 0, tb = stream;                // tile being computed: batch item, tile inside it
-    while (tb >= tiles_per_b && b < p.B) {
-        tb -= tiles_per_b;
-        ++b;
-    }
-    while (b < p.B) {
-        const long long n0 = (long long)tb * WS_PN;
-        f32x16 acc[NPT][RT];
-#pragma unroll
-        for (int j = 0; j < NPT; ++j)
-#pragma unroll
-            for (int t = 0; t < RT; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[j][t][r] = 0.f;
-
-        auto run_phase = [&](auto PH) {
-            constexpr int phase = decltype(PH)::value;
-            constexpr int npieces = (G::cum(phase + 1) - G::cum(phase)) * PW;     // DMA pieces this phase issues
-            constexpr int pps = (npieces + KSP - 1) / KSP;                         // ... per k16 step
-            wait_vm<PW * (D + G::cum(phase) - phase - 1)>();   // my pieces of this slot have landed ...
-            block_sync();                                      // ... and everybody's; the regions issued into below are free
-            const uint32_t rb = lds0 + q_reg * REG_BYTES;
-            if (++q_reg == R) q_reg = 0;
-            // lane 16 G + 4 q + pp of a half reads, for k rows q (+ 4), the 4 pixels 16 (pp & 1) + 8 G + 4 (pp >> 1) ..
-            const int l = opaque_lane();
-            const int rowq = (l & 15) >> 2;
-            const int cl = 2 * (l & 1) + ((l >> 4) & 1), rot = 4 * ((rowq >> 1) & 1);
-            const uint32_t common = rb + 128 * (8 * (l >> 5) + rowq) + 8 * ((l >> 1) & 1);
-            const uint32_t a0 = common + 16 * ((cl + rot) & 7), a1 = common + 16 * ((4 + cl + rot) & 7);
-            u32x2 xr[2][NPT][2];
-            auto issue_reads = [&](auto S) {
-                constexpr int s = decltype(S)::value;
-                if (WS_EXP(16)) return;
-                xr[s & 1][0][0] = lds_read_tr16<s * 2048>(a0);
-                xr[s & 1][0][1] = lds_read_tr16<s * 2048 + 512>(a0);
-                xr[s & 1][1][0] = lds_read_tr16<s * 2048>(a1);
-                xr[s & 1][1][1] = lds_read_tr16<s * 2048 + 512>(a1);
-            };
-            auto step = [&](auto S) {
-                constexpr int s = decltype(S)::value;
-                if constexpr (s + 1 < KSP) {
-                    issue_reads(std::integral_constant<int, s + 1>{});
-                    wait_lgkm<4>();
-                } else {
-                    wait_lgkm<0>();
-                }
-#pragma unroll
-                for (int j = 0; j < NPT; ++j) {
-                    if (WS_EXP(2)) continue;
-                    const u32x4 xx = {xr[s & 1][j][0][0], xr[s & 1][j][0][1], xr[s & 1][j][1][0], xr[s & 1][j][1][1]};
-                    const bf16x8 xfrag = __builtin_bit_cast(bf16x8, xx);
-#pragma unroll
-                    for (int t = 0; t < RT; ++t)
-                        acc[j][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xfrag, wf[phase * KSP + s][t], acc[j][t], 0, 0, 0);
-                }
-                // DMA issue in the shadow of the matrix work
-#pragma unroll
-                for (int i = s * pps; i < (s + 1) * pps && i < npieces; ++i) issue_piece();
-            };
-            issue_reads(std::integral_constant<int, 0>{});
-            [&]<int... S>(std::integer_sequence<int, S...>) { (step(std::integral_constant<int, S>{}), ...); }(
-                std::make_integer_sequence<int, KSP>{});
-        };
-        run_phase(std::integral_constant<int, 0>{});
-        if constexpr (NPH >= 2) run_phase(std::integral_constant<int, 1>{});
-        if constexpr (NPH >= 3) run_phase(std::integral_constant<int, 2>{});
-
-        // ---- second input: its NIN regions are the next slots of the ring ----
-        int in_reg0 = 0;
-        if constexpr (HAS_IN) {
-            wait_vm<PW * D>();
-            block_sync();
-            in_reg0 = q_reg;
-            q_reg += NIN;
-            if (q_reg >= R) q_reg -= R;
-        }
-
-        // ---- epilogue: every lane owns 16 consecutive pixels of one row per accumulator ----
-        if (p.rowstats && b != rs_b) {
-            flush_rowstats();
-            rs_b = b;
-        }
-        if (WS_EXP(1)) {
-#pragma unroll
-            for (int j = 0; j < NPT; ++j)
-#pragma unroll
-                for (int t = 0; t < RT; ++t) keep_alive(acc[j][t]);
-        } else {
-            const int l = opaque_lane();
-            const int ml = l & 31, h = l >> 5;
-            const long long px_l = n0 + 16 * h;                                 // + 32 j
-            const long long off_l = ((long long)b * p.M + m_first + ml) * p.P + px_l;     // + 32 t P + 32 j
-            unsigned short* yl = reinterpret_cast<unsigned short*>(p.y) + off_l;
-            unsigned short* al = reinterpret_cast<unsigned short*>(p.aux_out) + off_l;
-#pragma unroll
-            for (int j = 0; j < NPT; ++j) {
-                const bool ok0 = px_l + 32 * j < p.P, ok1 = px_l + 32 * j + 8 < p.P;
-#pragma unroll
-                for (int t = 0; t < RT; ++t) {
-                    const bool row_ok = m_first + 32 * t + ml < p.M;
-                    const long long off = (long long)(32 * t) * p.P + 32 * j;
-                    float v[16];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) v[r] = acc[j][t][r] + bias_t[t];
-                    auto store = [&](unsigned short* dst) {
-                        u32x4 lo, hi;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) {
-                            lo[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
-                            hi[i] = pack_bf16x2(v[8 + 2 * i], v[8 + 2 * i + 1]);
-                        }
-                        if (row_ok && ok0) *reinterpret_cast<u32x4*>(dst + off) = lo;
-                        if (row_ok && ok1) *reinterpret_cast<u32x4*>(dst + off + 8) = hi;
-                    };
-                    if (p.aux_out) store(al);
-                    if (p.gelu) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = gelu_f(v[r]);
-                    }
-                    if constexpr (HAS_IN) {
-                        const int mloc = wave * 32 * RT + 32 * t + ml;
-                        int reg = in_reg0 + mloc / IN_ROWS;
-                        if (reg >= R) reg -= R;
-                        const int rr = mloc % IN_ROWS;
-                        const uint32_t ib = lds0 + reg * REG_BYTES + 128 * rr;
-                        const u32x4 i0 = lds_read_b128<0>(ib + 16 * ((4 * j + 2 * h + (rr >> 1)) & 7));
-                        const u32x4 i1 = lds_read_b128<0>(ib + 16 * ((4 * j + 2 * h + 1 + (rr >> 1)) & 7));
-                        wait_lgkm<0>();
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            const uint32_t w = i < 4 ? i0[i & 3] : i1[i & 3];
-                            const float e0 = __uint_as_float(w << 16), e1 = __uint_as_float(w & 0xFFFF0000u);
-                            if (mul_gelu_grad) {
-                                v[2 * i] *= gelu_grad_f(e0);
-                                v[2 * i + 1] *= gelu_grad_f(e1);
-                            } else {
-                                v[2 * i] += e0;
-                                v[2 * i + 1] += e1;
-                            }
-                        }
-                    }
-                    store(yl);
-                    if (p.rowstats) {
-                        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-                        for (int g = 0; g < 2; ++g) {
-                            if (g == 0 ? ok0 : ok1) {
-#pragma unroll
-                                for (int i = 0; i < 8; i += 2) {
-                                    const uint32_t pk = pack_bf16x2(v[8 * g + i], v[8 * g + i + 1]);
-                                    const float a = __uint_as_float(pk << 16), c2 = __uint_as_float(pk & 0xFFFF0000u);
-                                    s1 += a + c2;
-                                    s2 = fmaf(a, a, fmaf(c2, c2, s2));
-                                }
-                            }
-                        }
-                        rs1[t] += s1;
-                        rs2[t] += s2;
-                    }
-                }
-            }
-        }
-        tb += nstreams;
-        while (tb >= tiles_per_b && b < p.B) {
-            tb -= tiles_per_b;
-            ++b;
-        }
-    }
-    flush_rowstats();
-    wait_vm0();      // nothing may be in flight into LDS when the workgroup's LDS is released
-}
-
-template <int KSP, int NPH, bool HAS_IN>
-static int pce_ws_launch(const PceParams& p, hipStream_t st, int ncu) {
-    using G = WsGeom<KSP, NPH, HAS_IN>;
-    static const bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(pce_ws_kernel<KSP, NPH, HAS_IN>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
-        return true;
-    }();
-    (void)once;
-    const int unit = 8 * p.npass;                       // workgroups w and w + 8 (same XCD) share a tile sequence
-    long long grid = (long long)(ncu / unit) * unit;
-    if (grid < unit) grid = unit;
-    hipLaunchKernelGGL((pce_ws_kernel<KSP, NPH, HAS_IN>), dim3((unsigned)grid), dim3(WS_THREADS), G::LDS, st, p);
-    return 0;
-}
 
 // ---- weight image ----------------------------------------------------------------------------------------------
 // element (pass, k16 step ks, row tile rt, lane, j)  <-  A[m][k],  m = pass*64*TH + rt*32 + (lane & 31),
@@ -1153,7 +670,7 @@ static bool pce_config(int M, int K, PceCfg* c) {
     c->NPH = nph > 3 ? 6 : nph;                         // built for 1, 2, 3 and 6 phases (4 and 5 pad to six)
     c->TH = M > 128 ? 6 : (M > 64 ? 2 : 1);
     c->npass = mk::ceil_div(M, 64 * c->TH);
-    return true;
+    return c->npass <= 4;                               // M <= 1536: four passes of 384 rows (the bias copy in LDS is sized for four)
 }
 static long long pce_image_core_bytes(const PceCfg& c) { return (long long)c.npass * c.NPH * c.KSP * 2 * c.TH * 1024; }
 
@@ -1205,7 +722,7 @@ extern "C" int mk_pce_pack(const void* w, int w_dtype, int transpose, int M, int
     MK_REQUIRE(w && img, "null pointer");
     MK_REQUIRE(w_dtype == 0 || w_dtype == 1, "w_dtype must be 0 (fp32) or 1 (bf16)");
     PceCfg c;
-    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768; M <= 384 when K > 384)");
+    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768, M <= 1536)");
     MK_REQUIRE(ldw >= (transpose ? M : K), "leading dimension too small");
     const long long total = (pce_image_core_bytes(c) + 64) / 2;
     const int spp = c.NPH * c.KSP;
@@ -1240,8 +757,7 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
     MK_REQUIRE((P % 8) == 0, "P = H*W must be a multiple of 8 (16-byte row alignment)");
     MK_REQUIRE(((uintptr_t)x & 15) == 0 && ((uintptr_t)wimg & 15) == 0, "x and the weight image must be 16-byte aligned");
     PceCfg c;
-    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768; M <= 384 when K > 384)");
-    MK_REQUIRE(c.npass <= 4, "M <= 1536 (four passes of 384 rows)");
+    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768, M <= 1536)");
     static const int pexp = [] { const char* e = getenv("MK_PCE_EXP"); return e ? atoi(e) : 0; }();
     MK_REQUIRE(!(addend && aux_in), "addend and aux_in are exclusive");
     MK_REQUIRE(!addend_affine || addend, "addend_affine needs an addend");
@@ -1293,32 +809,6 @@ extern "C" int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const fl
         p.split = 0;        // likewise
         p.Mb = M;
         bool done = false;
-        // weights resident in registers when they fit (K <= 384, 384-row halves): MK_PCE_WS=0 keeps the streaming kernel
-        const int use_ws = [] { const char* e = getenv("MK_PCE_WS"); return e ? atoi(e) : 0; }();   // 0 never (default), 1 where the microbenchmark says it pays, 2 wherever it fits
-        // (measured, tools/pce_bench.py, back-to-back launches: ahead of the streaming kernel for K > 128 -- 0.46 vs 0.50 ms for
-        // 384 -> 384 and 0.85 vs 0.94 for 384 -> 768 at 721 x 1440 -- but behind it where the output dominates (73 -> 384: 0.33
-        // vs 0.24, its 16-byte store pieces against 64-byte row segments) and, with a second input, on short launches (ring
-        // depth 5 instead of 9).  Inside the training step, where every launch follows a weight pack and starts cold, its
-        // fixed cost (288 KB of fragments per workgroup before the first MFMA) eats the gain: 15.0 vs 14.7 ms per step over
-        // the 56 launches, so the streaming kernel stays the default.)
-        const long long ws_tiles_per_cu = (P + WS_PN - 1) / WS_PN * batch / pce_cu_count();
-        const bool ws_pays = use_ws == 2 || (K > 128 && !((addend || aux_in) && ws_tiles_per_cu < 16));
-        if (use_ws && ws_pays && !addend_affine && c.TH == 6 && K > 64 && K <= 384) {
-            PceParams w = p;
-            w.tiles_per_b = (P + WS_PN - 1) / WS_PN;
-            MK_REQUIRE(w.tiles_per_b * batch < 2147483647LL, "too many pixel tiles");
-            w.ntiles = w.tiles_per_b * batch;
-            const bool has_in = p.addend || p.aux_in;
-            const int ncu = pce_cu_count();
-#define MK_WS_CASE(COND, KSP_, NPH_)                                                      \
-            if (!done && (COND)) {                                                        \
-                if (has_in) pce_ws_launch<KSP_, NPH_, true>(w, st, ncu);                  \
-                else pce_ws_launch<KSP_, NPH_, false>(w, st, ncu);                        \
-                done = true;                                                              \
-            }
-            MK_WS_CASE(K <= 80, 5, 1) MK_WS_CASE(K <= 128, 8, 1) MK_WS_CASE(K <= 256, 8, 2) MK_WS_CASE(K <= 384, 8, 3)
-#undef MK_WS_CASE
-        }
 #define MK_PCE_CASE(KSP_, NPH_, TH_) \
         if (!done && c.KSP == KSP_ && c.NPH == NPH_ && c.TH == TH_) {                                         \
             if (p.addend || p.aux_in) pce_launch<KSP_, NPH_, TH_, true>(p, st);                               \

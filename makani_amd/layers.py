@@ -182,7 +182,7 @@ def conv_plus_instance_norm(conv, x, z, sums, norm):
     else:
         return None
     x3 = _engine_field(x)
-    if x3 is None or not ops.pce_supported(conv.out_channels, conv.in_channels) or conv.out_channels != z.shape[1]:
+    if x3 is None or not ops.pce_supported_train(conv.out_channels, conv.in_channels) or conv.out_channels != z.shape[1]:
         return None
     B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
     if tuple(z.shape) != (B, conv.out_channels, H, W):
@@ -271,7 +271,7 @@ class Conv1x1(nn.Conv2d):
         from . import ops
         B, H, W = x.shape[0], x.shape[-2], x.shape[-1]
         x3 = _engine_field(x) if x.dim() == 4 else None
-        if x3 is not None and ops.pce_supported(self.out_channels, self.in_channels):
+        if x3 is not None and ops.pce_supported_train(self.out_channels, self.in_channels):
             a3 = None
             if addend is not None:
                 a3 = addend.contiguous().view(B, self.out_channels, H * W).to(torch.bfloat16)
@@ -335,8 +335,8 @@ def run_pointwise_chain(mods, x, skip_last_bias=False, want_row_sums=False):
     if pat is not None and x.dim() == 4:
         fc1, fc2 = pat
         x3 = _engine_field(x)
-        if (x3 is not None and ops.pce_supported(fc1.out_channels, fc1.in_channels)
-                and ops.pce_supported(fc2.out_channels, fc2.in_channels)):
+        if (x3 is not None and ops.pce_supported_train(fc1.out_channels, fc1.in_channels)
+                and ops.pce_supported_train(fc2.out_channels, fc2.in_channels)):
             with torch.autocast("cuda", enabled=False):
                 y, sums = _PceMLP.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias,
                                         want_row_sums)

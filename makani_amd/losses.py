@@ -258,4 +258,8 @@ class LossHandler(nn.Module):
         chw = (chw * self.multistep_weight).reshape(1, -1) if self.training else chw.reshape(1, -1)
         if isinstance(self.loss_obj, GeometricLpLoss):
             self.loss_obj.uniform_chw = self._uniform[bool(self.training)]
+        if isinstance(self.loss_obj, GeometricH1Loss):
+            # the H1 loss reduces over channels itself ([B] norms): its ``mask`` is per SAMPLE, the per-channel weights of
+            # the Lp family do not apply (losses.py:331-345); passing them broadcast only for B == 1 or B == C
+            return self.loss_obj(prd, tar)
         return self.loss_obj(prd, tar, chw)

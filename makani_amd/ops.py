@@ -173,7 +173,11 @@ def legendre_x3_image(table, nlat, inverse):
         cache[key] = entry = [img, ev]
         return img
     if entry[1] is not None:
-        if entry[1].query():
+        if torch.cuda.is_current_stream_capturing():
+            # an event query is illegal inside a stream capture; ordering behind the build is harmless (and a no-op
+            # once the build has finished)
+            torch.cuda.current_stream().wait_event(entry[1])
+        elif entry[1].query():
             entry[1] = None                     # built and finished: nothing to order any more
         else:
             torch.cuda.current_stream().wait_event(entry[1])
@@ -339,39 +343,25 @@ def conv1x1_wgrad_raw(gy, x3):
     b, o, p = gy.shape
     i = x3.shape[1]
     gw = torch.zeros(o, i, dtype=torch.float32, device=x3.device)
-    lib = _lib.load()
-    fn = lib.mk_conv1x1_wgrad if os.environ.get("MK_WGRAD", "blocks") != "os" else lib.mk_conv1x1_wgrad_os
-    _lib.check(fn(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, _stream()), "mk_conv1x1_wgrad")
+    _lib.check(_lib.load().mk_conv1x1_wgrad(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, _stream()),
+               "mk_conv1x1_wgrad")
     return gw
-
-
-def conv1x1_supported(x3, a):
-    """bf16 [B, K, P] field and [M, K] matrix with 16-byte aligned rows."""
-    return (x3.is_cuda and x3.dtype == torch.bfloat16 and a.dtype == torch.bfloat16 and x3.shape[1] % 8 == 0
-            and x3.shape[2] % 8 == 0)
-
-
-def conv1x1_fwd_raw(a, x3, addend=None):
-    """y[b] = a @ x3[b] (+ addend[b]):  a [M, K] bf16, x3 [B, K, P] bf16 -> [B, M, P] bf16 (HIP bf16 MFMA GEMM)."""
-    _need_cuda(a, x3)
-    assert a.is_contiguous() and x3.is_contiguous() and a.dtype == torch.bfloat16 and x3.dtype == torch.bfloat16
-    b, k, p = x3.shape
-    m = a.shape[0]
-    assert a.shape[1] == k
-    if addend is not None:
-        assert addend.is_contiguous() and addend.dtype == torch.bfloat16 and tuple(addend.shape) == (b, m, p)
-    y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
-    _lib.check(_lib.load().mk_conv1x1_fwd(a.data_ptr(), x3.data_ptr(), addend.data_ptr() if addend is not None else None,
-                                          y.data_ptr(), b, m, k, p, _stream()), "mk_conv1x1_fwd")
-    return y
 
 
 # ----------------------------------------------------------------------------
 # pixel-column engine (csrc/pce.hip): 1x1 convolutions with fused epilogues
 # ----------------------------------------------------------------------------
 def pce_supported(m, k):
-    """Shapes the engine is built for: K <= 768, and M <= 384 when K > 384."""
+    """One GEMM ``[m, k] @ [k, P]`` the engine is built for: K <= 768, M <= 1536."""
     return _lib.load().mk_pce_image_bytes(int(m), int(k)) > 0
+
+
+def pce_supported_train(out_channels, in_channels):
+    """A 1x1 convolution the engine can run in BOTH directions: forward ``[out, in]`` and the data gradient, the
+    transposed GEMM ``[in, out]`` (K' = out <= 768, M' = in <= 1536).  Layers that pass only the forward check
+    (e.g. 768 -> 1536, the fc1 of ``sfno_dhealy_73ch_edim768``) must take the fallback path as a whole: the
+    autograd node packs the transposed image in backward."""
+    return pce_supported(out_channels, in_channels) and pce_supported(in_channels, out_channels)
 
 
 def pce_pack(w, transpose=False):

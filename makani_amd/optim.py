@@ -56,13 +56,16 @@ class FusedAdam:
             else:
                 self._small.append((p, v))
         self.opt = None
+        self._own_groups = [dict(self.defaults, params=[])]
         if self._small:
             self.opt = torch.optim.Adam([v for _, v in self._small], lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
                                         fused=all(v.is_cuda for _, v in self._small))
 
     @property
     def param_groups(self):
-        return self.opt.param_groups if self.opt is not None else [dict(self.defaults)]
+        """ONE persistent list (torch's for the small tensors, else the optimizer's own): a scheduler that writes
+        ``group["lr"]`` reaches both the torch optimizer and the streaming passes, which read group 0."""
+        return self.opt.param_groups if self.opt is not None else self._own_groups
 
     def zero_grad(self, set_to_none=True):
         for st in self._big:
@@ -88,7 +91,7 @@ class FusedAdam:
         g = self._grad_like_param(st["p"])
         if g is None:
             return
-        hp = self.param_groups[0] if self.opt is not None else self.defaults
+        hp = self.param_groups[0]
         lr, (b1, b2), eps, wd = hp["lr"], hp["betas"], hp["eps"], hp["weight_decay"]
         gf = _flat_storage_view(torch.view_as_real(g) if g.is_complex() else g)
         assert gf is not None and gf.dtype == torch.float32 and gf.numel() == st["flat"].numel()
@@ -138,6 +141,11 @@ class FusedAdam:
                 "big": [{"m": st["m"], "v": st["v"], "step": st["step"]} for st in self._big]}
 
     def load_state_dict(self, sd):
+        if not isinstance(sd, dict) or set(sd) != {"small", "big"}:
+            raise ValueError("FusedAdam.load_state_dict: unrecognised layout (expected keys {'small', 'big'}; a plain "
+                             "torch.optim.Adam state dict cannot be mapped onto the split small / large tensor state)")
+        if len(sd["big"]) != len(self._big):
+            raise ValueError(f"FusedAdam.load_state_dict: {len(sd['big'])} large-tensor states for {len(self._big)} tensors")
         if self.opt is not None and sd.get("small") is not None:
             self.opt.load_state_dict(sd["small"])
         for st, src in zip(self._big, sd.get("big", [])):

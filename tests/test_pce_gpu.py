@@ -20,14 +20,6 @@ def _rel(a, b):
     return (torch.linalg.norm(a.double() - b.double()) / torch.linalg.norm(b.double())).item()
 
 
-@pytest.fixture(params=["streaming", "stationary"], autouse=True)
-def engine_variant(request, monkeypatch):
-    """Every test runs on both kernels of the engine: MK_PCE_WS=0 keeps the weight-streaming kernel, 2 takes the
-    weight-stationary one wherever the shape fits it (64 < K <= 384, M > 128); the default picks by measured speed."""
-    monkeypatch.setenv("MK_PCE_WS", "0" if request.param == "streaming" else "2")
-    return request.param
-
-
 # (M, K, P, batch): production channel counts on small pixel counts; ragged pixel tiles (P % 128 != 0), partial row
 # tiles (73), two passes (768 rows), two K phases (768 -> 384), tiny test-net sizes; the last two give a two-pass layer at
 # least one tile per workgroup, which is when the passes of a tile go to workgroup PAIRS (MK_PCE_SPLIT): whole and ragged

@@ -139,17 +139,6 @@ def main():
             print(f"{'conv1x1_wgrad':22s} {f'{O}x{I}x{P}':22s} {ms:8.3f} ms (min {b:7.3f})  {tf:9.1f} TFLOP/s bf16  {gb:8.1f} GB/s unique",
                   flush=True)
             del gyb, xb2, gw
-    if not only or "conv_fwd" in only:
-        for (M, K, P) in ((768, 384, 115200), (384, 768, 115200), (384, 384, 115200), (768, 384, 1038240),
-                          (384, 768, 1038240), (384, 384, 1038240)):
-            a = (torch.randn(M, K, device=dev) / K ** 0.5).to(torch.bfloat16)
-            xb3 = torch.randn(1, K, P, device=dev).to(torch.bfloat16)
-            for name, fn in (("conv1x1_fwd[hip]", lambda: ops.conv1x1_fwd_raw(a, xb3)), ("conv1x1_fwd[blas]", lambda: torch.mm(a, xb3[0]))):
-                ms, b = timeit(fn, args.iters)
-                tf = 2.0 * M * K * P / (ms * 1e-3) / 1e12
-                gb = 2.0 * (M + K) * P / (ms * 1e-3) / 1e9
-                print(f"{name:22s} {f'{M}x{K}x{P}':22s} {ms:8.3f} ms (min {b:7.3f})  {tf:9.1f} TFLOP/s bf16  {gb:8.1f} GB/s", flush=True)
-            del a, xb3
 
 
 if __name__ == "__main__":
