@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Headline benchmark: SFNO forward+backward samples/s, 73 channels on 721x1440 (BASELINE.json).
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W          (N > 1 without torchrun: starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 One step = zero_grad -> forward under bf16 autocast (spectral path fp32, as the reference) ->
@@ -159,8 +159,11 @@ class KernelTimer:
                     ach, peak, unit, bound = d["bytes"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
             else:
                 ach, peak, unit, bound = d["work"] / sec / 1e9, PEAK_HBM_GBS, "GB/s", "hbm"
+            work = d["bytes"] if (d["unit"] == "flop" and bound == "hbm") else d["work"]
+            roof_ms = work / (peak * (1e9 if unit == "GB/s" else 1e12)) * 1e3 / steps
             out[name] = {"bound": bound, "achieved": round(ach, 2), "peak": peak, "unit": unit,
                          "frac": round(ach / peak, 4), "ms_per_step": round(d["ms"] / steps, 3),
+                         "roofline_ms_per_step": round(roof_ms, 4),
                          "launches_per_step": d["launches"] / steps,
                          "avg_launch_ms": round(d["ms"] / d["launches"], 4)}
         return out
@@ -295,6 +298,18 @@ def main():
                     help="capture forward+loss+backward in a HIP graph and replay it (reference: trainer.py:84-152, "
                          "optimizer step outside the graph); kernel timing then comes from an eager pre-pass")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N ranks as a torch.distributed.run child BEFORE anything here touches
+        # the GPU (no exec of a GPU-initialised process, no HIP context in this parent) and hand its exit code on
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     from makani_amd import comm, mappings
     from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
@@ -464,6 +479,24 @@ def main():
             roof = {"kernel": dom, "bound": k["bound"], "achieved": k["achieved"], "peak": k["peak"], "unit": k["unit"],
                     "frac": k["frac"], "traffic": _measured_traffic(dom), "traffic_unit": "HBM bytes per launch (PMC)",
                     "avg_launch_ms": k["avg_launch_ms"]}
+        step_roof = None
+        if kernels:
+            # step-level roofline: sum over the step's op census of (algorithmic work / the peak that binds it), over the
+            # measured step time.  Timed launches bring their own work (KernelTimer); the streaming passes without a
+            # wrapper are counted from the configuration: instance norms (block: norm0 + GELU forward = 3 row passes of the
+            # bf16 field, norm1's forward rides in GEMM epilogues, each backward = 5), Adam (28 bytes per real parameter:
+            # p, g, m, v read, p, m, v written), the loss (pred bf16 + target fp32 read, gradient written: 14 bytes/px)
+            E, nblk = CONFIG["embed_dim"], CONFIG["num_layers"]
+            px_full = lat_loc * 1440
+            px_low = net.h_loc * net.w_loc
+            nreal = sum(p.numel() * (2 if p.is_complex() else 1) for p in net.parameters())
+            census = {n: k["roofline_ms_per_step"] for n, k in kernels.items() if "roofline_ms_per_step" in k}
+            census["instance_norm"] = 13 * E * 2 * B * (px_full + (nblk - 1) * px_low) / (PEAK_HBM_GBS * 1e9) * 1e3
+            census["adam"] = 28.0 * nreal / (PEAK_HBM_GBS * 1e9) * 1e3
+            census["loss"] = 14.0 * 73 * B * px_full / (PEAK_HBM_GBS * 1e9) * 1e3
+            total = sum(census.values())
+            step_roof = {"sum_work_over_peak_ms": round(total, 3), "frac": round(total / (1e3 * elapsed / args.steps), 4),
+                         "census_ms": {n: round(v, 3) for n, v in census.items()}}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
@@ -482,7 +515,7 @@ def main():
                        "micro_batches": nmb, "python_gc": "disabled in the timed region",
                        "adam": ("large tensors updated on a side stream as their gradients arrive, joined in opt.step()"
                                 if (adam_overlap and not args.graph) else "after backward")},
-            "roofline": roof, "cpu_baseline": cpu, "kernels": kernels,
+            "roofline": roof, "step_roofline": step_roof, "cpu_baseline": cpu, "kernels": kernels,
             "kernel_timing": ("HIP events: all kernels over the last %d warm-up step(s), the roofline kernel over the timed region"
                               % n_probe) if n_probe else ("HIP events over an eager pre-pass" if args.graph else
                                                           "HIP events over the timed region"),
