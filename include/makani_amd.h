@@ -226,13 +226,18 @@ int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const float* wrow
  * in MLP / EncoderDecoder / skip connections (layers.py:95-128,158-183; sfnonet.py:207,463). */
 int mk_conv1x1_wgrad(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P,
                      void* stream);
+/* The same with an activation applied to x while it is staged: x_act = 1 multiplies with GELU(x) (exact erf form,
+ * rounded to bf16).  The weight gradient of the SECOND convolution of an MLP (layers.py:158-206) from the kept
+ * pre-activation: with mk_pce_mlp the activated hidden field is never written.  cout <= 384. */
+int mk_conv1x1_wgrad_act(const void* gy, const void* x, float* gw, int batch, int cout, int cin, long long P, int x_act,
+                         void* stream);
 /* Pixel-column engine (csrc/pce.hip): the same 1x1 convolutions as one persistent kernel per GEMM with the
  * pointwise passes of layers.py:86-216 / sfnonet.py:239-267 folded into the epilogue:
  *   acc[b][m][p] = sum_k A[m][k] * x[b][k][p] (+ bias[m]);   aux_out <- acc (bf16, optional: the pre-activation kept for
  *   the backward pass);   v = gelu ? GELU(acc) : acc;   v *= GELU'(aux_in[b][m][p]) (optional: backward of the activation);
  *   y = v (+ addend[b][m][p]).
  * A comes pre-packed (mk_pce_pack) as the MFMA fragment image of W [M][K] (forward) or of W^T (data gradient).
- * x, y, addend, aux_* are bf16 [B][C][P], P a multiple of 8; K <= 768, and M <= 384 when K > 384; bias is fp32 [M]
+ * x, y, addend, aux_* are bf16 [B][C][P], P a multiple of 8; K <= 768, M <= 1536; bias is fp32 [M]
  * (or NULL); addend and aux_in are exclusive.
  * Replaces hipBLASLt's mm/addmm behind nn.Conv2d(.., 1) and the separate bias+GELU passes. */
 long long mk_pce_image_bytes(int M, int K);
@@ -249,6 +254,24 @@ int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, con
 int mk_pce_gemm_ex(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const float* addend_affine,
                    const void* aux_in, void* aux_out, int gelu, double* rowstats, int batch, int M, int K, long long P,
                    void* stream);
+/* Fused two-layer node (csrc/pce_mlp.hip): conv1x1 -> GELU -> conv1x1 of `MLP` / `EncoderDecoder` (layers.py:86-216; call
+ * sites sfnonet.py:207,379,463) as ONE launch with the Hd-row hidden field kept on chip:
+ *   mode 0 (forward):   mid_out = A1 x + b1  (bf16 [B][Hd][P], the pre-activation kept for backward);
+ *                       y = A2 GELU(mid_out) (+ b2);   rowstats_y as in mk_pce_gemm_ex (or NULL)
+ *   mode 1 (backward):  mid_out = (A1 x) * GELU'(mid_in)  (x = the output gradient, mid_in = the kept pre-activation:
+ *                       mid_out is the gradient w.r.t. the pre-activation, operand of the first weight gradient);
+ *                       y = A2 mid_out (the input gradient);   rowsum_mid [B][Hd] (double, zeroed by the call, or NULL) receives
+ *                       the pixel sums of mid_out = the gradient of b1
+ * A1 [Hd][K1] and A2 [M][Hd] come packed by mk_pce_mlp_pack (forward: W1, W2; backward: W2^T, W1^T -- `*_transposed` says
+ * the array holds the transpose, i.e. a1 is [K1][Hd] / a2 is [Hd][M]).  K1 <= 384, Hd <= 768, M <= 384; x, y, mid_* bf16,
+ * P a multiple of 8, biases fp32 or NULL. */
+long long mk_pce_mlp_image_bytes(int M, int Hd, int K1);
+int mk_pce_mlp_pack(const void* a1, int a1_transposed, int lda1, const void* a2, int a2_transposed, int lda2,
+                    int w_dtype /* 0 fp32, 1 bf16 */, int M, int Hd, int K1, void* img, void* stream);
+int mk_pce_mlp(const void* x, const void* wimg, void* y, void* mid_out, const void* mid_in, const float* b1, const float* b2,
+               double* rowstats_y, double* rowsum_mid, int mode, int batch, int M, int Hd, int K1, long long P, void* stream);
+/* Profiling aid (tools/mlp_stamps.py; build with -DMK_MLP_STAMPS, MK_MLP_DBG=1): s_memtime stamps of workgroup 0, 4 x 128. */
+int mk_pce_mlp_debug_stamps(unsigned long long* out512);
 /* Per-row coefficients of an instance norm from its row sums: stats[row] = (mean, rstd) (the form mk_instnorm_bwd takes),
  * affine[row] = (rstd * weight[c], bias[c] - mean * rstd * weight[c]); count = elements per row (global, when sharded). */
 int mk_instnorm_coeffs(const double* sums, const float* weight, const float* bias, float* stats, float* affine, int rows,

@@ -64,6 +64,12 @@ SIGNATURES = {
     "mk_wmse_fwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_wmse_bwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_conv1x1_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
+    "mk_conv1x1_wgrad_act": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _c_int, _vp]),
+    "mk_pce_mlp_image_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
+    "mk_pce_mlp_pack": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "mk_pce_mlp": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int,
+                            ctypes.c_longlong, _vp]),
+    "mk_pce_mlp_debug_stamps": (_c_int, [_vp]),
     "mk_pce_image_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "mk_pce_pack": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
     "mk_pce_gemm": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
@@ -86,7 +92,10 @@ def load():
     if _LIB is not None:
         return _LIB
     path = _build.LIB
-    if _build.stale():
+    override = os.environ.get("MK_LIB_OVERRIDE")        # A/B builds of the kernels (tools only): load this file as it is
+    if override:
+        path = override
+    elif _build.stale():
         # missing, or older than a source / header: rebuild when hipcc is here, never run a stale library silently
         if _build.have_hipcc():
             path = _build.build(verbose=False)

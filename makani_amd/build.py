@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmakani_amd.so")
 STAMP = LIB + ".stamp"
-SOURCES = ["host.cpp", "fft.hip", "gemm.hip", "gemm_x3.hip", "layout.hip", "diag.hip", "pointwise.hip", "conv_gemm.hip", "pce.hip", "adam.hip"]
+SOURCES = ["host.cpp", "fft.hip", "gemm.hip", "gemm_x3.hip", "layout.hip", "diag.hip", "pointwise.hip", "conv_gemm.hip", "pce.hip", "pce_mlp.hip", "adam.hip"]
 HEADERS = ["common.h", "fft_split.h", "lds_dma.h", "pce_common.h", os.path.join("..", "..", "include", "makani_amd.h")]
 
 

@@ -129,4 +129,38 @@ __device__ __forceinline__ u32x2 lds_read_b64(uint32_t addr) {
     return v;
 }
 
+
+// returnless LDS float add (several lanes may hit one address: the LDS serialises them)
+__device__ __forceinline__ void lds_add_f32(uint32_t addr, float v) {
+    asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// 16-byte global load the compiler does not track: no s_waitcnt is inserted for it, the CALLER orders its use behind
+// its own vmcnt wait (the compiler's waitcnt pass turns a load carried across a loop iteration into vmcnt(0), which
+// would drain the LDS-DMA ring)
+__device__ __forceinline__ u32x4 gload16_untracked(const void* p) {
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n (smaller immediates are stricter: n is clamped to 15)
+__device__ __forceinline__ void wait_vm_upto(int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 13: asm volatile("s_waitcnt vmcnt(13)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(15)" ::: "memory"); break;
+    }
+}
 }  // namespace pce

@@ -336,15 +336,17 @@ def diag_contract(x, w):
     return _DiagContract.apply(x.contiguous(), w.contiguous())
 
 
-def conv1x1_wgrad_raw(gy, x3):
-    """gW[o][i] = sum_{b,p} gy[b][o][p] x3[b][i][p]: bf16 [B,O,P], [B,I,P] -> fp32 [O,I] (HIP bf16 MFMA kernel)."""
+def conv1x1_wgrad_raw(gy, x3, x_gelu=False):
+    """gW[o][i] = sum_{b,p} gy[b][o][p] act(x3[b][i][p]): bf16 [B,O,P], [B,I,P] -> fp32 [O,I] (HIP bf16 MFMA kernel);
+    ``x_gelu``: act = exact GELU rounded to bf16, applied while x3 is staged (x3 is then the kept pre-activation of an MLP;
+    O <= 384)."""
     _need_cuda(gy, x3)
     assert gy.is_contiguous() and x3.is_contiguous() and gy.dtype == torch.bfloat16 and x3.dtype == torch.bfloat16
     b, o, p = gy.shape
     i = x3.shape[1]
     gw = torch.zeros(o, i, dtype=torch.float32, device=x3.device)
-    _lib.check(_lib.load().mk_conv1x1_wgrad(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, _stream()),
-               "mk_conv1x1_wgrad")
+    _lib.check(_lib.load().mk_conv1x1_wgrad_act(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, int(bool(x_gelu)),
+                                                _stream()), "mk_conv1x1_wgrad_act")
     return gw
 
 
@@ -377,6 +379,57 @@ def pce_pack(w, transpose=False):
     _lib.check(lib.mk_pce_pack(w.data_ptr(), 0 if w.dtype == torch.float32 else 1, int(bool(transpose)), m, k, w.stride(0),
                                img.data_ptr(), _stream()), "mk_pce_pack")
     return img
+
+
+def pce_mlp_supported(m, hd, k1):
+    """Shapes of the fused conv -> GELU -> conv node (csrc/pce_mlp.hip): K1 <= 384, Hd <= 768, M <= 384."""
+    return _lib.load().mk_pce_mlp_image_bytes(int(m), int(hd), int(k1)) > 0
+
+
+def pce_mlp_pack(a1, a1_transposed, a2, a2_transposed):
+    """Weight stream image of the fused node: ``A1 [Hd, K1]`` = ``a1`` (or ``a1^T`` when ``a1_transposed``: ``a1`` is
+    ``[K1, Hd]``), ``A2 [M, Hd]`` = ``a2`` (or ``a2^T``: ``a2`` is ``[Hd, M]``).  Returns ``(image, M, Hd, K1)``."""
+    _need_cuda(a1, a2)
+    assert a1.dim() == 2 and a2.dim() == 2 and a1.stride(1) == 1 and a2.stride(1) == 1 and a1.dtype == a2.dtype
+    assert a1.dtype in (torch.float32, torch.bfloat16)
+    hd, k1 = (a1.shape[1], a1.shape[0]) if a1_transposed else (a1.shape[0], a1.shape[1])
+    m, hd2 = (a2.shape[1], a2.shape[0]) if a2_transposed else (a2.shape[0], a2.shape[1])
+    assert hd == hd2, "the two matrices do not share the hidden dimension"
+    lib = _lib.load()
+    nbytes = lib.mk_pce_mlp_image_bytes(m, hd, k1)
+    if nbytes <= 0:
+        raise ValueError(f"pce_mlp_pack: unsupported shape M={m}, Hd={hd}, K1={k1}")
+    img = torch.empty(nbytes, dtype=torch.uint8, device=a1.device)
+    _lib.check(lib.mk_pce_mlp_pack(a1.data_ptr(), int(bool(a1_transposed)), a1.stride(0), a2.data_ptr(), int(bool(a2_transposed)),
+                                   a2.stride(0), 0 if a1.dtype == torch.float32 else 1, m, hd, k1, img.data_ptr(), _stream()),
+               "mk_pce_mlp_pack")
+    return img, m, hd, k1
+
+
+def pce_mlp(x3, packed, mode, b1=None, b2=None, pre=None, want_row_sums=False, want_mid_sums=False):
+    """The fused node on bf16 ``[B, K1, P]`` fields (``mk_pce_mlp``).  ``mode`` 0: returns ``(y, pre[, sums])`` with
+    ``pre = A1 x + b1`` and ``y = A2 gelu(pre) + b2``; ``mode`` 1 (``x3`` = output gradient, ``pre`` = the kept pre-activation):
+    returns ``(gx, gpre[, gpre_sums])`` with ``gpre = (A1 x) * gelu'(pre)``, ``gx = A2 gpre`` and the fp64 ``[B * Hd]`` pixel sums
+    of ``gpre``."""
+    img, m, hd, k1 = packed
+    _need_cuda(x3, img)
+    assert x3.dim() == 3 and x3.is_contiguous() and x3.dtype == torch.bfloat16 and x3.shape[1] == k1
+    b, _, p = x3.shape
+    if mode == 1:
+        assert pre is not None and pre.is_contiguous() and pre.dtype == torch.bfloat16 and tuple(pre.shape) == (b, hd, p)
+    bf1 = None if b1 is None else b1.detach().float().contiguous()
+    bf2 = None if b2 is None else b2.detach().float().contiguous()
+    assert (bf1 is None or bf1.numel() == hd) and (bf2 is None or bf2.numel() == m)
+    y = torch.empty(b, m, p, dtype=torch.bfloat16, device=x3.device)
+    mid = torch.empty(b, hd, p, dtype=torch.bfloat16, device=x3.device)
+    sums = torch.empty(b * m, 2, dtype=torch.float64, device=x3.device) if want_row_sums else None
+    msum = torch.empty(b * hd, dtype=torch.float64, device=x3.device) if want_mid_sums else None
+    _lib.check(_lib.load().mk_pce_mlp(x3.data_ptr(), img.data_ptr(), y.data_ptr(), mid.data_ptr(),
+                                      None if pre is None else pre.data_ptr(), None if bf1 is None else bf1.data_ptr(),
+                                      None if bf2 is None else bf2.data_ptr(), None if sums is None else sums.data_ptr(),
+                                      None if msum is None else msum.data_ptr(), int(mode), b, m, hd, k1, p, _stream()),
+               "mk_pce_mlp")
+    return (y, mid) + ((sums,) if want_row_sums else ()) + ((msum,) if want_mid_sums else ())
 
 
 _ZERO_BIAS = {}
