@@ -283,6 +283,52 @@ def cpu_full_step():
     return round(dt, 2)
 
 
+def _synthetic_setup(dev, rank=0, world=1, lat_loc=721, lat_off=0):
+    """Weights, fields and row weights of the benchmark (one definition for main(), the golden-loss tool and its test)."""
+    from makani_amd import ops
+    torch.manual_seed(333 + rank)               # different synthetic data per rank
+    B = world
+    inp = torch.randn(B, 73, lat_loc, 1440, device=dev)
+    tar = torch.randn(B, 73, lat_loc, 1440, device=dev)
+    _, wq = ops.quadrature("equiangular", 721)
+    wq = torch.from_numpy(wq / wq.sum() / 1440.0).float()[lat_off:lat_off + lat_loc].to(dev)
+    return inp, tar, wq.contiguous()
+
+
+def first_step_losses(with_oracle=False):
+    """The loss of the benchmark's first step at N = 1 (bf16 autocast, freshly initialised seed-333 weights), and -- with
+    ``with_oracle`` -- the fp32 CPU oracle's loss for the same weights and fields (one oracle forward: ~20 s on 16 cores)."""
+    from makani_amd import ops
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(333)
+    net = SphericalFourierNeuralOperatorNet(**CONFIG)
+    state = {k: v.clone() for k, v in net.state_dict().items()} if with_oracle else None
+    net = net.to(dev)
+    inp, tar, wq_row = _synthetic_setup(dev)
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        pred = net(inp)
+    out = {"bf16_engine_loss": float(ops.weighted_mse(pred, tar, wq_row, 1.0 / 73).item())}
+    if with_oracle:
+        from oracle import spectral as osp
+        torch.set_num_threads(_host_cores())
+        ref = osp.SphericalFourierNeuralOperatorNet(**{k: v for k, v in CONFIG.items()
+                                                       if k not in ("spectral_transform", "filter_type", "pos_embed")})
+        ref.load_state_dict(state, strict=True)
+        with torch.no_grad():
+            po = ref(inp.cpu())
+        w = wq_row.cpu().double().view(1, 1, -1, 1)
+        out["oracle_fp32_loss"] = float((((po.double() - tar.cpu().double()) ** 2) * w).sum().item() / 73)
+    return out
+
+
+def _golden_first_loss():
+    try:
+        return json.load(open(os.path.join(ROOT, "tests", "golden", "bench_first_loss.json")))
+    except (OSError, ValueError):
+        return None
+
+
 # ----------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -344,12 +390,8 @@ def main():
     B = world                                   # weak scaling: one sample per GPU
     lat_loc = net.inp_shape_loc[0]
     lat_off = sum(net.trans_down.lat_shapes[:hrank]) if hsize > 1 else 0
-    torch.manual_seed(333 + rank)               # ... different synthetic data per rank
-    inp = torch.randn(B, 73, lat_loc, 1440, device=dev)
-    tar = torch.randn(B, 73, lat_loc, 1440, device=dev)
-    _, wq = ops.quadrature("equiangular", 721)
-    wq = torch.from_numpy(wq / wq.sum() / 1440.0).float()[lat_off:lat_off + lat_loc].to(dev).view(1, 1, -1, 1)
-    wq_row = wq.view(-1).contiguous()           # quadrature weight per local latitude row (fused loss kernel)
+    inp, tar, wq_row = _synthetic_setup(dev, rank, world, lat_loc, lat_off)    # ... different synthetic data per rank; wq_row:
+                                                                               # quadrature weight per local latitude row
 
     timer = KernelTimer()
     if not args.no_kernel_timing:
@@ -402,11 +444,20 @@ def main():
             runner, nmb = None, 1
             opt.zero_grad(set_to_none=True)
 
+    # value check of the timed configuration: the loss of the very first step (initial weights) against the value recorded in
+    # tests/golden/bench_first_loss.json, which tests/test_parity_gpu.py::test_bench_first_step_loss pins to the fp32 CPU oracle
+    first_loss = None
+    if world == 1 and runner is None and args.warmup > 0:
+        first_loss = float(step().item())
+        args_warm_left = args.warmup - 1
+    else:
+        args_warm_left = args.warmup
+
     timed_step = step
     pre_kernels = None
-    n_probe = 0 if (args.no_kernel_timing or args.graph) else min(args.warmup, 2)
-    for i in range(args.warmup):
-        timer.enabled = i >= args.warmup - n_probe
+    n_probe = 0 if (args.no_kernel_timing or args.graph) else min(args_warm_left, 2)
+    for i in range(args_warm_left):
+        timer.enabled = i >= args_warm_left - n_probe
         step()
     torch.cuda.synchronize()
     timer.enabled = False
@@ -521,6 +572,14 @@ def main():
                                                           "HIP events over the timed region"),
             "loss": round(loss.item(), 6),
         }
+        golden = _golden_first_loss()
+        if first_loss is not None:
+            chk = {"first_step_loss": round(first_loss, 6)}
+            if golden is not None:
+                g = golden["bf16_engine_loss"]
+                chk.update(golden=g, oracle_fp32=golden.get("oracle_fp32_loss"), rel_diff=round(abs(first_loss - g) / g, 6),
+                           ok=bool(abs(first_loss - g) <= 2e-3 * g))
+            line["loss_check"] = chk
         print(json.dumps(line), flush=True)
     if world > 1:
         comm.cleanup()

@@ -172,6 +172,43 @@ def test_sfno_full_config_backward_vs_oracle(dev):
     worst = max(errs, key=errs.get)
     assert errs[worst] < 5 * TOL, (worst, errs[worst])
 
+    # The SAME net, data and loss in the mode bench.py times: bf16 autocast, i.e. the pointwise stack on the pixel-column engine
+    # (bf16 fields between the spectral ops, which stay fp32-accurate) -- against the fp32 oracle step above.  Tolerances are
+    # bf16 ones: every field of the pointwise stack is rounded to 8 significant bits (2^-9 = 2e-3 relative per value) about 60
+    # times between input and output; measured (MI355X): 2.1e-2 on the output, 2.7e-5 on the loss, 4.4e-2 on the input gradient and
+    # on the worst sampled parameter gradient (blocks.0.filter.filter.weight).
+    loss_o = ((yo - tar) ** 2).mean().item()
+    net.zero_grad(set_to_none=True)
+    xb = x.to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = net(xb)
+    loss_b = ((yb.float() - tar.to(dev)) ** 2).mean()
+    loss_b.backward()
+    e_y, e_l, e_x = rel(yb.float(), yo), abs(loss_b.item() - loss_o) / loss_o, rel(xb.grad, xo.grad)
+    errs_b = {n: rel(pn[n].grad, po[n].grad, floor=1e-1 * scale) for n in sample}
+    worst_b = max(errs_b, key=errs_b.get)
+    print(f"bf16 engine mode vs fp32 oracle at 721x1440: output {e_y:.2e}, loss {e_l:.2e}, input grad {e_x:.2e}, "
+          f"worst sampled parameter grad {worst_b} {errs_b[worst_b]:.2e}")
+    assert yb.dtype == torch.bfloat16
+    assert e_y < 3e-2 and e_l < 1e-3 and e_x < 6e-2
+    assert errs_b[worst_b] < 8e-2, (worst_b, errs_b[worst_b])
+
+
+def test_bench_first_step_loss(dev):
+    """The value check behind bench.py's `loss_check`: the loss of the benchmark's first step (its own weights, fields and
+    area-weighted MSE; bf16 autocast through the engine) against the fp32 CPU oracle on the same weights and fields, and both
+    against the recorded pair in tests/golden/bench_first_loss.json that bench.py compares itself with at run time."""
+    import json
+    import os
+    import bench
+    vals = bench.first_step_losses(with_oracle=True)
+    assert abs(vals["bf16_engine_loss"] - vals["oracle_fp32_loss"]) <= 5e-3 * vals["oracle_fp32_loss"], vals
+    path = os.path.join(os.path.dirname(__file__), "golden", "bench_first_loss.json")
+    assert os.path.exists(path), "tests/golden/bench_first_loss.json is missing (tools/make_bench_golden.py)"
+    gold = json.load(open(path))
+    assert abs(vals["oracle_fp32_loss"] - gold["oracle_fp32_loss"]) <= 1e-4 * gold["oracle_fp32_loss"], (vals, gold)
+    assert abs(vals["bf16_engine_loss"] - gold["bf16_engine_loss"]) <= 2e-3 * gold["bf16_engine_loss"], (vals, gold)
+
 
 @pytest.mark.parametrize("operator_type,activation,bias", [("diagonal", "real", False), ("l-dependant", "cartesian", True),
                                                             ("diagonal", "modulus", True)])
