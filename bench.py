@@ -101,7 +101,7 @@ class KernelTimer:
             t, i, o = tri_pairs(lloc, mloc, l_off, m_off), out.shape[1], out.shape[2]
             return 8.0 * i * o * t * batch, "flop", 8.0 * t * batch * (i + o) + 8.0 * i * o * lloc
 
-        def conv_wgrad_work(out, gy, x3):
+        def conv_wgrad_work(res, gy, x3, **_):
             # arithmetic intensity O*I/(O+I) <= 256 flop/byte at the production shapes, below the bf16 ridge point
             # (2517 TFLOP/s / 8 TB/s = 315): HBM is the roof -- both bf16 operands read once, the fp32 gradient written
             b, o, p = gy.shape

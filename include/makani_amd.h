@@ -243,6 +243,12 @@ int mk_conv1x1_wgrad_act(const void* gy, const void* x, float* gw, int batch, in
 long long mk_pce_image_bytes(int M, int K);
 int mk_pce_pack(const void* w, int w_dtype /* 0 fp32, 1 bf16 */, int transpose, int M, int K, int ldw, void* img,
                 void* stream);
+/* All weight images of a net in ONE launch: desc_dev = n descriptors of 10 x int64 {weight pointer, dtype (0 fp32 / 1 bf16),
+ * transpose, M, K, leading dimension, TH, steps per pass, core elements (the last three from mk_pce_pack_layout), first element in
+ * the arena}, sorted by first element; image e occupies mk_pce_image_bytes(M, K) bytes from arena + 2 * first (the 64 zero bytes
+ * included).  Replaces the per-call mk_pce_pack of every 1x1 convolution of a training step (56 launches at the SFNO config). */
+int mk_pce_pack_layout(int M, int K, long long* out3);
+int mk_pce_pack_batch(const void* desc_dev, int n, void* arena, long long total_elements, void* stream);
 int mk_pce_gemm(const void* x, const void* wimg, void* y, const float* bias, const void* addend, const void* aux_in,
                 void* aux_out, int gelu, int batch, int M, int K, long long P, void* stream);
 /* The same with two more seams to the instance norms around the convolutions (sfnonet.py:262-267):

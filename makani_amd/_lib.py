@@ -72,6 +72,8 @@ SIGNATURES = {
     "mk_pce_mlp_debug_stamps": (_c_int, [_vp]),
     "mk_pce_image_bytes": (ctypes.c_longlong, [_c_int, _c_int]),
     "mk_pce_pack": (_c_int, [_vp, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),
+    "mk_pce_pack_layout": (_c_int, [_c_int, _c_int, _vp]),
+    "mk_pce_pack_batch": (_c_int, [_vp, _c_int, _vp, ctypes.c_longlong, _vp]),
     "mk_pce_gemm": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_pce_gemm_ex": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_instnorm_coeffs": (_c_int, [_vp, _vp, _vp, _vp, _vp, _c_int, _c_int, ctypes.c_longlong, ctypes.c_float, _vp]),

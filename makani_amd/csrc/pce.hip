@@ -616,14 +616,9 @@ __global__ __launch_bounds__(PT, 2) void pce_kernel(PceParams p) {
 // element (pass, k16 step ks, row tile rt, lane, j)  <-  A[m][k],  m = pass*64*TH + rt*32 + (lane & 31),
 // k = 16 ks + 8 (lane >> 5) + j;  A = W or W^T;  one slot = the 2 TH fragments of one k16 step; 32 zero elements at the end
 template <typename T>
-__global__ void pce_pack_kernel(const T* __restrict__ w, int transpose, int M, int K, int ldw, int TH, int steps_per_pass,
-                                unsigned short* __restrict__ img, long long core, long long total) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= total) return;
-    if (idx >= core) {
-        img[idx] = 0;
-        return;
-    }
+__device__ __forceinline__ unsigned short pce_pack_element(const T* __restrict__ w, int transpose, int M, int K, int ldw, int TH,
+                                                           int steps_per_pass, long long core, long long idx) {
+    if (idx >= core) return 0;
     const int j = (int)(idx & 7);
     const int lane = (int)((idx >> 3) & 63);
     long long f = idx >> 9;                 // fragment index
@@ -634,7 +629,37 @@ __global__ void pce_pack_kernel(const T* __restrict__ w, int transpose, int M, i
     const int k = 16 * ks + 8 * (lane >> 5) + j;
     float v = 0.f;
     if (m < M && k < K) v = (float)(transpose ? w[(long long)k * ldw + m] : w[(long long)m * ldw + k]);
-    img[idx] = f32_to_bf16_bits(v);
+    return f32_to_bf16_bits(v);
+}
+
+template <typename T>
+__global__ void pce_pack_kernel(const T* __restrict__ w, int transpose, int M, int K, int ldw, int TH, int steps_per_pass,
+                                unsigned short* __restrict__ img, long long core, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    img[idx] = pce_pack_element(w, transpose, M, K, ldw, TH, steps_per_pass, core, idx);
+}
+
+// Many images in one launch (mk_pce_pack_batch): descriptor e = 10 x int64 {weight pointer, dtype, transpose, M, K, ldw, TH,
+// steps per pass, core elements, first element in the arena}; the images lie back to back, descriptor n holds the total
+struct PackDesc {
+    long long w, dtype, transpose, M, K, ldw, TH, spp, core, first;
+};
+__global__ void pce_pack_batch_kernel(const PackDesc* __restrict__ desc, int n, unsigned short* __restrict__ arena, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    int lo = 0, hi = n;                     // last descriptor whose first element is <= idx
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (desc[mid].first <= idx) lo = mid;
+        else hi = mid;
+    }
+    const PackDesc d = desc[lo];
+    const long long local = idx - d.first;
+    arena[idx] = d.dtype == 0
+        ? pce_pack_element(reinterpret_cast<const float*>(d.w), (int)d.transpose, (int)d.M, (int)d.K, (int)d.ldw, (int)d.TH, (int)d.spp, d.core, local)
+        : pce_pack_element(reinterpret_cast<const __hip_bfloat16*>(d.w), (int)d.transpose, (int)d.M, (int)d.K, (int)d.ldw, (int)d.TH, (int)d.spp,
+                           d.core, local);
 }
 
 // zero bias for layers without one (the epilogue's bias load is unconditional); first use must not be inside a capture
@@ -733,6 +758,26 @@ extern "C" int mk_pce_pack(const void* w, int w_dtype, int transpose, int M, int
     else
         hipLaunchKernelGGL(pce_pack_kernel<__hip_bfloat16>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream,
                            (const __hip_bfloat16*)w, transpose, M, K, ldw, c.TH, spp, (unsigned short*)img, total - 32, total);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int mk_pce_pack_layout(int M, int K, long long* out3) {
+    MK_REQUIRE(out3, "null pointer");
+    PceCfg c;
+    MK_REQUIRE(pce_config(M, K, &c), "unsupported shape (K <= 768, M <= 1536)");
+    out3[0] = c.TH;
+    out3[1] = (long long)c.NPH * c.KSP;
+    out3[2] = pce_image_core_bytes(c) / 2;
+    return 0;
+}
+
+extern "C" int mk_pce_pack_batch(const void* desc_dev, int n, void* arena, long long total_elements, void* stream) {
+    MK_REQUIRE(desc_dev && arena && n > 0 && total_elements > 0, "bad arguments");
+    const long long nblk = (total_elements + 255) / 256;
+    MK_REQUIRE(nblk < 2147483647LL, "arena too large");
+    hipLaunchKernelGGL(pce_pack_batch_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const PackDesc*)desc_dev, n,
+                       (unsigned short*)arena, total_elements);
     MK_LAUNCH_CHECK();
     return 0;
 }

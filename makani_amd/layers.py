@@ -82,6 +82,13 @@ class _PointwiseConv(torch.autograd.Function):
         return gx, gw, ga
 
 
+def _step_items(w):
+    """What the backward pass of a convolution with weight ``w`` takes from the open ``ops.EngineArena`` scope: (transposed
+    image, zeroed gradient buffer), each None outside a scope (the backward pass then packs / allocates itself)."""
+    from . import ops
+    return ops.arena_image(w, True), (ops.arena_grad_buffer(w) if w.requires_grad else None)
+
+
 def _row_sums(t3):
     """sum over (batch, pixels) of a [B, C, P] field -> fp32 [C] (the HIP row-sum pass of the instance norm)."""
     from . import ops
@@ -99,6 +106,7 @@ class _PceConv(torch.autograd.Function):
         ctx.save_for_backward(x3, w)
         ctx.has = (bias is not None, addend is not None)
         ctx.bias_dtype = None if bias is None else bias.dtype
+        ctx.step = _step_items(w)
         return ops.pce_gemm(x3, ops.pce_pack(w), w.shape[0], bias=bias, addend=addend)
 
     @staticmethod
@@ -108,10 +116,13 @@ class _PceConv(torch.autograd.Function):
         has_bias, has_addend = ctx.has
         gy = gy.contiguous()
         gx = gw = gb = None
+        # taken once: no reference may survive this call (autograd adopts gw only as its sole owner); a second backward pass
+        # through the same node packs / allocates for itself
+        (wimg_t, gbuf), ctx.step = (ctx.step or (None, None)), None
         if ctx.needs_input_grad[0]:
-            gx = ops.pce_gemm(gy, ops.pce_pack(w, transpose=True), w.shape[1])
+            gx = ops.pce_gemm(gy, wimg_t if wimg_t is not None else ops.pce_pack(w, transpose=True), w.shape[1])
         if ctx.needs_input_grad[1]:
-            gw = ops.conv1x1_wgrad_raw(gy, x3).to(w.dtype)
+            gw = ops.conv1x1_wgrad_raw(gy, x3, out=gbuf).to(w.dtype)
         if has_bias and ctx.needs_input_grad[2]:
             gb = _row_sums(gy).to(ctx.bias_dtype)
         return gx, gw, gb, (gy if has_addend else None)
@@ -139,6 +150,7 @@ class _PceConvNormAdd(torch.autograd.Function):
         ctx.save_for_backward(x3, w, z4, stats, wf if wf is not None else empty, bf if bf is not None else empty)
         ctx.cfg = (None if bias is None else bias.dtype, None if nw is None else nw.dtype, None if nb is None else nb.dtype,
                    group, cnt)
+        ctx.step = _step_items(w)
         return y
 
     @staticmethod
@@ -149,10 +161,13 @@ class _PceConvNormAdd(torch.autograd.Function):
         B, C, H, W = z4.shape
         gy = gy.contiguous()
         gx = gw = gb = None
+        # taken once: no reference may survive this call (autograd adopts gw only as its sole owner); a second backward pass
+        # through the same node packs / allocates for itself
+        (wimg_t, gbuf), ctx.step = (ctx.step or (None, None)), None
         if ctx.needs_input_grad[0]:
-            gx = ops.pce_gemm(gy, ops.pce_pack(w, transpose=True), w.shape[1])
+            gx = ops.pce_gemm(gy, wimg_t if wimg_t is not None else ops.pce_pack(w, transpose=True), w.shape[1])
         if ctx.needs_input_grad[1]:
-            gw = ops.conv1x1_wgrad_raw(gy, x3).to(w.dtype)
+            gw = ops.conv1x1_wgrad_raw(gy, x3, out=gbuf).to(w.dtype)
         if bias_dtype is not None and ctx.needs_input_grad[2]:
             gb = _row_sums(gy).to(bias_dtype)
         gz, gnw, gnb = ops.instance_norm_backward(z4, gy.view(B, C, H, W), stats, wf if nw_dtype is not None else None,
@@ -212,6 +227,7 @@ class _PceMLP(torch.autograd.Function):
         y, sums = y if want_row_sums else (y, x3.new_empty(0, dtype=torch.float64))
         ctx.save_for_backward(x3, w1, w2, pre, h)
         ctx.cfg = (None if b1 is None else b1.dtype, None if b2 is None else (b2.dtype, tuple(b2.shape)), bool(apply_b2))
+        ctx.step = _step_items(w1) + _step_items(w2)
         ctx.mark_non_differentiable(sums)
         return y, sums
 
@@ -223,14 +239,16 @@ class _PceMLP(torch.autograd.Function):
         gy = gy.contiguous()
         need_gb1 = b1_dtype is not None and ctx.needs_input_grad[2]
         fused_gb1 = need_gb1 and w2.shape[1] <= 768
-        gpre = ops.pce_gemm(gy, ops.pce_pack(w2, transpose=True), w2.shape[1], aux_in=pre, want_row_sums=fused_gb1)
+        (w1img_t, g1buf, w2img_t, g2buf), ctx.step = (ctx.step or (None, None, None, None)), None
+        gpre = ops.pce_gemm(gy, w2img_t if w2img_t is not None else ops.pce_pack(w2, transpose=True), w2.shape[1], aux_in=pre,
+                            want_row_sums=fused_gb1)
         if fused_gb1:       # the bias gradient is the pixel sum of gpre: a by-product of the launch that wrote it
             gpre, gsum = gpre
         gx = gw1 = gb1 = gw2 = gb2 = None
         if ctx.needs_input_grad[0]:
-            gx = ops.pce_gemm(gpre, ops.pce_pack(w1, transpose=True), w1.shape[1])
+            gx = ops.pce_gemm(gpre, w1img_t if w1img_t is not None else ops.pce_pack(w1, transpose=True), w1.shape[1])
         if ctx.needs_input_grad[1]:
-            gw1 = ops.conv1x1_wgrad_raw(gpre, x3).to(w1.dtype)
+            gw1 = ops.conv1x1_wgrad_raw(gpre, x3, out=g1buf).to(w1.dtype)
         if need_gb1:
             if fused_gb1:
                 g1 = gsum.view(gy.shape[0], -1, 2)[..., 0]
@@ -238,7 +256,7 @@ class _PceMLP(torch.autograd.Function):
             else:
                 gb1 = _row_sums(gpre).to(b1_dtype)
         if ctx.needs_input_grad[3]:
-            gw2 = ops.conv1x1_wgrad_raw(gy, h).to(w2.dtype)
+            gw2 = ops.conv1x1_wgrad_raw(gy, h, out=g2buf).to(w2.dtype)
         if b2_info is not None and ctx.needs_input_grad[4]:
             gb2 = _row_sums(gy).to(b2_info[0]) if apply_b2 else torch.zeros(b2_info[1], dtype=b2_info[0], device=gy.device)
         return gx, gw1, gb1, gw2, gb2, None, None

@@ -8,6 +8,7 @@ step is captured in ``makani/utils/trainer.py:84-152``.
 Private layouts (see the header): ``xf`` = complex64 ``[M, K, BC]``, spectrum =
 complex64 ``[L, M, BC]`` (channels last), dhconv weight = complex64 ``[L, I, O]``.
 """
+import ctypes
 import math
 import os
 
@@ -336,15 +337,115 @@ def diag_contract(x, w):
     return _DiagContract.apply(x.contiguous(), w.contiguous())
 
 
-def conv1x1_wgrad_raw(gy, x3, x_gelu=False):
+# ----------------------------------------------------------------------------
+# per-step arena of the pointwise stack: every packed weight image in ONE launch, every weight-gradient buffer in ONE fill
+# ----------------------------------------------------------------------------
+_ACTIVE_ARENA = None
+
+
+class EngineArena:
+    """What the 1x1 convolutions of one net need per step besides their GEMMs, batched: the MFMA fragment images of every
+    weight in both orientations (``mk_pce_pack_batch``: one launch instead of one ``mk_pce_pack`` per GEMM) and the zeroed
+    fp32 buffers the weight-gradient kernels accumulate into (one fill instead of one per layer).
+
+    ``with arena.scope():`` around a forward pass refreshes the images from the CURRENT weights (always: no invalidation
+    protocol to get wrong) and makes ``pce_pack`` / ``conv1x1_wgrad_raw`` find them; the autograd nodes take what their
+    backward pass needs (transposed image, gradient buffer) while the scope is open.  Outside a scope -- a layer called on its
+    own, a checkpoint recomputation -- every call packs / allocates for itself as before."""
+
+    def __init__(self, weights):
+        self.weights = [w for w in weights if w.is_cuda and w.dim() == 2 and w.stride(1) == 1
+                        and w.dtype in (torch.float32, torch.bfloat16)]
+        lib = _lib.load()
+        rows, self.slots, off, goff = [], {}, 0, 0
+        self.gslots = {}
+        for w in self.weights:
+            for transpose in (False, True):
+                m, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
+                nbytes = lib.mk_pce_image_bytes(m, k)
+                if nbytes <= 0:
+                    continue
+                lay = (ctypes.c_longlong * 3)()
+                _lib.check(lib.mk_pce_pack_layout(m, k, lay), "mk_pce_pack_layout")
+                rows.append([w.data_ptr(), 0 if w.dtype == torch.float32 else 1, int(transpose), m, k, w.stride(0), lay[0], lay[1],
+                             lay[2], off])
+                self.slots[self._key(w, transpose)] = (off * 2, nbytes)
+                off += nbytes // 2
+            self.gslots[self._key(w, False)] = (goff, w.shape[0], w.shape[1])
+            goff += (w.numel() + 3) // 4 * 4           # 16-byte aligned buffers
+        self.total, self.gtotal = off, goff
+        self.n = len(rows)
+        dev = self.weights[0].device if self.weights else None
+        self.desc = torch.tensor(rows + [[0] * 9 + [off]], dtype=torch.int64).to(dev) if rows else None
+        self.images = torch.empty(2 * off, dtype=torch.uint8, device=dev) if rows else None
+        self.gbuf = None
+        self._prev = None
+
+    @staticmethod
+    def _key(w, transpose):
+        return (w.data_ptr(), tuple(w.shape), w.stride(0), w.dtype, bool(transpose))
+
+    def refresh(self, with_grad_buffers):
+        if self.n:
+            _lib.check(_lib.load().mk_pce_pack_batch(self.desc.data_ptr(), self.n, self.images.data_ptr(), self.total, _stream()),
+                       "mk_pce_pack_batch")
+        # a fresh buffer per step: the views handed out become the parameters' gradients and live as long as those do
+        self.gbuf = torch.zeros(self.gtotal, dtype=torch.float32, device=self.images.device) if (with_grad_buffers and self.gtotal) else None
+
+    def image(self, w, transpose):
+        slot = self.slots.get(self._key(w, transpose))
+        return None if slot is None else self.images[slot[0]:slot[0] + slot[1]]
+
+    def grad_buffer(self, w):
+        """Zeroed fp32 ``[out, in]`` buffer for the gradient of ``w`` -- once per step (a second request gets None: the
+        caller then allocates, e.g. a weight used twice in one forward pass)."""
+        slot = self.gslots.get(self._key(w, False))
+        if slot is None or self.gbuf is None or slot[0] in self._taken:
+            return None
+        self._taken.add(slot[0])
+        return self.gbuf[slot[0]:slot[0] + slot[1] * slot[2]].view(slot[1], slot[2])
+
+    def scope(self):
+        return _ArenaScope(self)
+
+
+class _ArenaScope:
+    def __init__(self, arena):
+        self.arena = arena
+
+    def __enter__(self):
+        global _ACTIVE_ARENA
+        self.arena._prev, _ACTIVE_ARENA = _ACTIVE_ARENA, self.arena
+        self.arena._taken = set()
+        self.arena.refresh(torch.is_grad_enabled())
+        return self.arena
+
+    def __exit__(self, *exc):
+        global _ACTIVE_ARENA
+        _ACTIVE_ARENA = self.arena._prev
+        return False
+
+
+def arena_image(w, transpose=False):
+    """The packed image of ``w`` from the open arena scope, or None."""
+    return None if _ACTIVE_ARENA is None else _ACTIVE_ARENA.image(w, transpose)
+
+
+def arena_grad_buffer(w):
+    return None if _ACTIVE_ARENA is None else _ACTIVE_ARENA.grad_buffer(w)
+
+
+def conv1x1_wgrad_raw(gy, x3, x_gelu=False, out=None):
     """gW[o][i] = sum_{b,p} gy[b][o][p] act(x3[b][i][p]): bf16 [B,O,P], [B,I,P] -> fp32 [O,I] (HIP bf16 MFMA kernel);
     ``x_gelu``: act = exact GELU rounded to bf16, applied while x3 is staged (x3 is then the kept pre-activation of an MLP;
-    O <= 384)."""
+    O <= 384).  ``out``: accumulate into this zeroed buffer instead of a fresh one."""
     _need_cuda(gy, x3)
     assert gy.is_contiguous() and x3.is_contiguous() and gy.dtype == torch.bfloat16 and x3.dtype == torch.bfloat16
     b, o, p = gy.shape
     i = x3.shape[1]
-    gw = torch.zeros(o, i, dtype=torch.float32, device=x3.device)
+    if out is not None:      # a zeroed fp32 [O, I] buffer (EngineArena.grad_buffer)
+        assert out.dtype == torch.float32 and tuple(out.shape) == (o, i) and out.is_contiguous()
+    gw = out if out is not None else torch.zeros(o, i, dtype=torch.float32, device=x3.device)
     _lib.check(_lib.load().mk_conv1x1_wgrad_act(gy.data_ptr(), x3.data_ptr(), gw.data_ptr(), b, o, i, p, int(bool(x_gelu)),
                                                 _stream()), "mk_conv1x1_wgrad_act")
     return gw
@@ -367,8 +468,12 @@ def pce_supported_train(out_channels, in_channels):
 
 
 def pce_pack(w, transpose=False):
-    """MFMA fragment image of A = w (``[M, K]``) or A = w^T (``w`` is ``[K, M]``); fp32 or bf16 weights."""
+    """MFMA fragment image of A = w (``[M, K]``) or A = w^T (``w`` is ``[K, M]``); fp32 or bf16 weights.  Inside an
+    ``EngineArena`` scope that holds ``w`` the image comes from the arena's batched launch."""
     _need_cuda(w)
+    img = arena_image(w, transpose)
+    if img is not None:
+        return img
     assert w.dim() == 2 and w.stride(1) == 1 and w.dtype in (torch.float32, torch.bfloat16)
     m, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
     lib = _lib.load()

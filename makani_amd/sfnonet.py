@@ -16,6 +16,7 @@ Spatial model parallelism (``comm.get_size("spatial") > 1``) selects the distrib
 filter runs on the HIP transforms with a torch channel MLP in between (``spectral_convolution.SpectralAttention``).
 """
 import math
+import os
 from functools import partial
 
 import torch
@@ -293,7 +294,33 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 x = checkpoint(blk, x, use_reentrant=False) if self.checkpointing >= 3 else blk(x)
         return x
 
+    def _engine_arena(self, x):
+        """The per-step arena of the pointwise stack (``ops.EngineArena``) when this call runs on the bf16 engine, else None."""
+        from . import ops
+        from .layers import Conv1x1
+        if not (x.is_cuda and x.dim() == 4 and os.environ.get("MK_ENGINE_ARENA", "1") != "0"):
+            return None
+        if not (x.dtype == torch.bfloat16 or (torch.is_autocast_enabled() and torch.get_autocast_dtype("cuda") == torch.bfloat16)):
+            return None
+        cached = self.__dict__.get("_arena")                # (convolutions, their weight pointers, arena): plain attribute, not state
+        if cached is None:
+            convs = [m for m in self.modules() if isinstance(m, Conv1x1)]
+        else:
+            convs = cached[0]
+        ptrs = [m.weight.data_ptr() for m in convs]
+        if cached is None or cached[1] != ptrs:             # first call, or a parameter's storage moved (.to(), .data = ...)
+            cached = (convs, ptrs, ops.EngineArena([m.weight2d() for m in convs if m.weight.is_cuda]))
+            self.__dict__["_arena"] = cached
+        return cached[2] if cached[2].n else None
+
     def forward(self, x):
+        arena = self._engine_arena(x)
+        if arena is None:
+            return self._forward(x)
+        with arena.scope():       # every weight image of the step in one launch, every weight-gradient buffer in one fill
+            return self._forward(x)
+
+    def _forward(self, x):
         if self.big_skip and self.out_shape == self.inp_shape and x.dtype == torch.float32 and x.dim() == 4:
             # the input feeds the encoder AND the big skip: cast it for the bf16 engine once, not once per consumer
             x3 = _engine_field(x)

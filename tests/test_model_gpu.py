@@ -218,6 +218,45 @@ def test_sfno_bf16_engine_gradients(dev):
     assert errs[worst] < 5e-2, (worst, errs[worst])
 
 
+def test_engine_arena_is_bit_identical_and_tracks_the_weights(dev, monkeypatch):
+    """The per-step arena (every packed weight image in one launch, every weight-gradient buffer in one fill, `ops.EngineArena`)
+    against the per-call path (MK_ENGINE_ARENA=0): same bits in the output, the same gradients; weights changed in place
+    between two steps -- through an optimizer, and behind autograd's back through `.data` -- are seen by the next step; a
+    repeated-weight net (repeat_layers = 2: two uses of one weight per step) still sums its gradients."""
+    from makani_amd import ops
+    from makani_amd.optim import FusedAdam
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    for extra in (dict(), dict(repeat_layers=2)):
+        torch.manual_seed(4)
+        kw = dict(inp_shape=(32, 64), out_shape=(32, 64), scale_factor=2, inp_chans=6, out_chans=5, embed_dim=32, num_layers=2, **extra)
+        net = SphericalFourierNeuralOperatorNet(**kw).to(dev)
+        x, tar = torch.randn(2, 6, 32, 64, device=dev), torch.randn(2, 5, 32, 64, device=dev)
+        opt = FusedAdam(net.parameters(), lr=1e-2)
+
+        def step():
+            net.zero_grad(set_to_none=True)
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                y = net(x)
+            ((y.float() - tar) ** 2).mean().backward()
+            return y.detach().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()}
+
+        for round_ in range(3):
+            monkeypatch.setenv("MK_ENGINE_ARENA", "1")
+            y1, g1 = step()
+            assert net.__dict__["_arena"][2].n > 0 and ops._ACTIVE_ARENA is None
+            monkeypatch.setenv("MK_ENGINE_ARENA", "0")
+            y0, g0 = step()
+            assert torch.equal(y1, y0), (extra, round_)
+            for n in g1:       # (the weight gradients are sums of fp32 atomics: equal up to the order of the additions)
+                assert rel(g1[n], g0[n]) < 1e-5, (extra, round_, n)
+            if round_ == 0:
+                opt.step()                                  # in-place update through the optimizer
+            else:
+                with torch.no_grad():
+                    net.encoder.fwd[0].weight.data.mul_(1.5)    # ... and behind autograd's back
+        del net, opt
+
+
 def test_hip_graph_capture_replay(dev):
     """The reference's capture sequence, literally (makani/utils/trainer.py:109-148): warm-ups on the capture stream,
     ``static_loss`` of the last warm-up still alive when ``capture_begin()`` runs (it is released inside the capture),

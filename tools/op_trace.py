@@ -45,3 +45,10 @@ for e in prof.key_averages(group_by_input_shape=True):
 rows.sort(reverse=True)
 for t, c, k, sh in rows[:int(os.environ.get('MK_TRACE_ROWS', '70'))]:
     print(f"{t / 1e3:8.3f} ms  x{c:4d}  {k[:60]:60s} {sh}")
+# the small launches, by the op that issued them (kernels of at most 10 us on average)
+print("\n# launches of <= 10 us average, by op")
+small = [(c, t, k, sh) for t, c, k, sh in rows if c > 0 and t / c <= 10.0 and not k.startswith("void ") and "anonymous namespace" not in k]
+small.sort(reverse=True)
+for c, t, k, sh in small[:60]:
+    print(f"x{c:4d}  {t / 1e3:7.3f} ms  {k[:60]:60s} {sh}")
+print(f"# kernels launched in the step: {sum(e.count for e in prof.key_averages() if e.device_time_total > 0 and ('void ' in e.key or 'anonymous namespace' in e.key or 'Memcpy' in e.key or 'Memset' in e.key))}")
