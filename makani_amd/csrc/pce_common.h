@@ -134,6 +134,16 @@ __device__ __forceinline__ u32x2 lds_read_b64(uint32_t addr) {
 __device__ __forceinline__ void lds_add_f32(uint32_t addr, float v) {
     asm volatile("ds_add_f32 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
+template <int OFF>
+__device__ __forceinline__ void lds_add_f32_off(uint32_t addr, float v) {
+    asm volatile("ds_add_f32 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ float lds_read_b32_off(uint32_t addr) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF) : "memory");
+    return v;
+}
 // 16-byte global load the compiler does not track: no s_waitcnt is inserted for it, the CALLER orders its use behind
 // its own vmcnt wait (the compiler's waitcnt pass turns a load carried across a loop iteration into vmcnt(0), which
 // would drain the LDS-DMA ring)

@@ -218,6 +218,38 @@ def test_sfno_bf16_engine_gradients(dev):
     assert errs[worst] < 5e-2, (worst, errs[worst])
 
 
+def test_sfno_bf16_fused_mlp_node(dev, monkeypatch):
+    """MK_MLP_FUSED=1: the MLP / encoder / decoder of the net on the fused conv -> GELU -> conv kernel (hidden field on chip, forward and
+    backward): output and every parameter gradient against the fp32 oracle at bf16 accuracy, and against the unfused engine path."""
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    from oracle import spectral as osp
+    torch.manual_seed(9)
+    kw = dict(inp_shape=(32, 64), out_shape=(32, 64), scale_factor=2, inp_chans=6, out_chans=5, embed_dim=32, num_layers=3)
+    ref = osp.SphericalFourierNeuralOperatorNet(**kw)
+    net = SphericalFourierNeuralOperatorNet(**kw).to(dev)
+    net.load_state_dict(ref.state_dict())
+    x, tar = torch.randn(2, 6, 32, 64), torch.randn(2, 5, 32, 64)
+    yo = ref(x)
+    ((yo - tar) ** 2).mean().backward()
+    po = dict(ref.named_parameters())
+    scale = float(np.median([torch.linalg.norm(_f64(p.grad)).item() for p in po.values()]))
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("MK_MLP_FUSED", fused)
+        net.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            y = net(x.to(dev))
+        ((y.float() - tar.to(dev)) ** 2).mean().backward()
+        res[fused] = (y.detach().float().clone(), {n: p.grad.detach().clone() for n, p in net.named_parameters()})
+        assert rel(y.float(), yo) < 3e-2
+        errs = {n: rel(p.grad, po[n].grad, floor=scale) for n, p in net.named_parameters()}
+        worst = max(errs, key=errs.get)
+        assert errs[worst] < 5e-2, (fused, worst, errs[worst])
+    assert rel(res["1"][0], res["0"][0]) < 1e-2
+    for n in res["1"][1]:
+        assert rel(res["1"][1][n], res["0"][1][n], floor=scale) < 2e-2, n
+
+
 def test_engine_arena_is_bit_identical_and_tracks_the_weights(dev, monkeypatch):
     """The per-step arena (every packed weight image in one launch, every weight-gradient buffer in one fill, `ops.EngineArena`)
     against the per-call path (MK_ENGINE_ARENA=0): same bits in the output, the same gradients; weights changed in place

@@ -29,16 +29,16 @@ for _ in range(3):
 torch.cuda.synchronize()
 buf = np.zeros(512, dtype=np.uint64)
 _lib.check(_lib.load().mk_pce_mlp_debug_stamps(buf.ctypes.data), "stamps")
-st = buf.reshape(4, 128).astype(np.int64)
+st = buf.reshape(8, 64).astype(np.int64)
 t0 = st[:, 0].min()
 names = ["tile"]
 for it in range(31):
     names += [f"it{it}A", f"it{it}B", f"it{it}C", f"it{it}D"]
-print("stamp     " + " ".join(f"w{i:<7d}" for i in range(4)) + "  (ticks since the first stamp; delta of wave 0 / wave 3 in brackets)")
+print("stamp     " + " ".join(f"w{i:<7d}" for i in range(8)) + "  (ticks since the first stamp; delta of wave 0 / wave 3 in brackets)")
 prev = None
-for i in range(128):
+for i in range(64):
     if st[:, i].max() == 0:
         break
-    d = "" if prev is None else f"[{int(st[0, i] - prev[0])} / {int(st[3, i] - prev[3])}]"
+    d = "" if prev is None else f"[{int(st[0, i] - prev[0])} / {int(st[4, i] - prev[4])}]"
     prev = st[:, i].copy()
     print(f"{names[i] if i < len(names) else '#' + str(i):9s} " + " ".join(f"{int(v - t0):<8d}" for v in st[:, i]) + "  " + d)
