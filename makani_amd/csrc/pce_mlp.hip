@@ -539,7 +539,7 @@ __global__ __launch_bounds__(QT, 2) void pce_mlp_kernel(MlpParams p) {
             auto stage2_half = [&]<int HALF>(auto& S, int buf, std::integral_constant<int, HALF>) __attribute__((always_inline)) {
                 constexpr int T0 = HALF * MTH, NT = (HALF == 0) ? MTH : MT - MTH, NF = 2 * NT;
                 if constexpr (!S1 && NT > 0) {
-                    constexpr int NFB = MK_MLP_NFB2;      // (the accumulators leave this role few registers)
+                    constexpr int NFB = 3;        // (the accumulators leave this role few registers; 2, 3, 4 in flight measured alike)
                     const uint32_t a = lds_addr(WB) + buf * SLOTB + NH1 * 1024 + lane * 16;
                     bf16x8 wf[NFB];
                     [&]<int... J>(std::integer_sequence<int, J...>) {
