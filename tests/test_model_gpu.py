@@ -245,7 +245,7 @@ def test_sfno_bf16_fused_mlp_node(dev, monkeypatch):
         errs = {n: rel(p.grad, po[n].grad, floor=scale) for n, p in net.named_parameters()}
         worst = max(errs, key=errs.get)
         assert errs[worst] < 5e-2, (fused, worst, errs[worst])
-    assert rel(res["1"][0], res["0"][0]) < 1e-2
+    assert rel(res["1"][0], res["0"][0]) < 2e-2
     for n in res["1"][1]:
         assert rel(res["1"][1][n], res["0"][1][n], floor=scale) < 2e-2, n
 
@@ -280,7 +280,7 @@ def test_engine_arena_is_bit_identical_and_tracks_the_weights(dev, monkeypatch):
             y0, g0 = step()
             assert torch.equal(y1, y0), (extra, round_)
             for n in g1:       # (the weight gradients are sums of fp32 atomics: equal up to the order of the additions)
-                assert rel(g1[n], g0[n]) < 1e-5, (extra, round_, n)
+                assert torch.equal(g1[n], g0[n]) or rel(g1[n], g0[n]) < 1e-5, (extra, round_, n)
             if round_ == 0:
                 opt.step()                                  # in-place update through the optimizer
             else:
