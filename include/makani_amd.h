@@ -221,6 +221,14 @@ int mk_wmse_fwd(const void* pred, int dtype, const float* tar, const float* wrow
 int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const float* wrow, const float* gloss, void* gpred,
                 long long rows, int H, int W, float scale, void* stream);
 
+/* The same convolutions on fp32 fields (no autocast), fp32-accurate on the bf16x3 engine of the spectral GEMMs (csrc/gemm_x3.hip):
+ *   mode 0:  c[b] = a b[b]            a [M][K] row-major (lda a multiple of 4, rows zero-padded to K rounded up to 4), b[b] [K][N] = the NCHW field (N = H*W even)
+ *   mode 1:  c[b] += a b[b]           (a skip connection folded into the GEMM: c holds the addend)
+ *   mode 2:  c += sum_b a[b] b[b]^T   a[b] [M][K], b[b] [N][K], K = H*W the contraction: the weight gradient (c zeroed by the caller, fp32 atomics)
+ * sa / sb / sc = batch strides in elements.  Replaces F.conv2d / its gradients behind nn.Conv2d(.., 1) in fp32 mode (layers.py:95-206). */
+int mk_conv1x1_x3(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K, long long N,
+                  int batch, long long sa, long long sb, long long sc, int mode, void* stream);
+
 /* gw[o][i] += sum over (b, p) of gy[b][o][p] * x[b][i][p]; gy, x bf16 [B][C][P] (P multiple of 8), gw fp32
  * [cout][cin] accumulated with atomics (caller zeroes it).  The weight gradient of nn.Conv2d(cin, cout, 1)
  * in MLP / EncoderDecoder / skip connections (layers.py:95-128,158-183; sfnonet.py:207,463). */

@@ -348,7 +348,9 @@ __device__ __forceinline__ void x3_mfma_step(const char* As, const char* Bs, con
 // writes 8-byte values, 256 B per row and wave.
 // The B operand streams from HBM: it is prefetched DB k-steps ahead through a ring of register sets (the
 // loop is unrolled DB times so ring slots are compile-time); the A operand (L2-resident panels) one ahead.
-template <int DB, class AS, class BS>
+// EPI: 0 = store (nontemporal), 1 = C += tile (read-modify-write by the one workgroup that owns the tile), 2 = atomic adds
+// (several workgroups contract disjoint k ranges into one tile)
+template <int DB, class AS, class BS, int EPI = 0>
 __device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int kt1, int rvalid, int cvalid, float* cbase,
                                         long long ldc, char* lds, int exp = 0) {
     const int tid = threadIdx.x, lane = tid & 63;
@@ -417,6 +419,16 @@ __device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int
             for (int r = 0; r < 16; ++r) {
                 const int row = wr * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
                 if (row < rvalid) {
+                    if constexpr (EPI == 1) {
+                        float2* d = reinterpret_cast<float2*>(cbase + (long long)row * ldc + col);
+                        const float2 o = *d;
+                        *d = make_float2(o.x + acc[a][0][r], o.y + acc[a][1][r]);
+                        continue;
+                    } else if constexpr (EPI == 2) {
+                        atomicAdd(cbase + (long long)row * ldc + col, acc[a][0][r]);
+                        if (col + 1 < cvalid) atomicAdd(cbase + (long long)row * ldc + col + 1, acc[a][1][r]);
+                        continue;
+                    }
 #ifndef MK_X3_PLAIN_STORE
                     // nontemporal: the streamed output does not push the re-used panels (Legendre tile images, dhconv operands)
                     // out of L2.  Isolated launches, same box: Legendre 0.120 / 0.107 -> 0.109 / 0.094 ms at 240 latitudes,
@@ -770,6 +782,106 @@ extern "C" int mk_dhconv_wgrad_x3(const float* x, const float* gy, float* gw, in
     const long long nblk = grid_blocks(lloc, p.tiles_m, p.tiles_n);
     MK_REQUIRE(nblk < 2147483647LL, "grid too large");
     hipLaunchKernelGGL(dhconv_wgrad_x3_kernel, dim3((unsigned)nblk), dim3(XT), X3_LDS, (hipStream_t)stream, p);
+    MK_LAUNCH_CHECK();
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------
+// 1x1 convolutions on fp32 fields (nn.Conv2d(.., 1) of MLP / EncoderDecoder / skips outside autocast: layers.py:86-216,
+// sfnonet.py:207,379,463) on the same bf16x3 engine: fp32-accurate products without a vendor GEMM.
+//   mode 0:  C[b] = A B[b]          A [M][K] row-major (K a multiple of 4), B[b] [K][N] k-major (the NCHW field, N = H*W even)
+//   mode 1:  C[b] += A B[b]         (the skip connection folded into the GEMM: C holds the addend)
+//   mode 2:  C += sum_b A[b] B[b]^T  A[b] [M][Kp], B[b] [N][Kp] both row-major over the contraction (the pixels): the weight
+//            gradient, the pixels cut into slabs of `kslab` k-steps, one workgroup per (tile, slab), fp32 atomics into C (zeroed by the caller)
+// ---------------------------------------------------------------------------
+namespace {
+struct ConvX3Params {
+    const float* a;
+    const float* b;
+    float* c;
+    long long lda, ldb, ldc, sa, sb, sc;
+    int M, K, N, nwork, tiles_m, tiles_n, nslab, kslab;
+};
+template <int MODE>
+__global__ __launch_bounds__(XT, 3) void conv_x3_kernel(ConvX3Params p) {
+    extern __shared__ __attribute__((aligned(16))) char lds_x3[];
+    const TileId t = decode_block(p.nwork, p.tiles_m, p.tiles_n);
+    if (!t.valid) return;
+    const int m0 = t.tm * XM, n0 = t.tn * XN;
+    if constexpr (MODE == 2) {
+        const int b = t.batch / p.nslab, slab = t.batch - b * p.nslab;
+        const int kt0 = slab * p.kslab, ktn = (p.K + XK - 1) / XK;
+        const int kt1 = kt0 + p.kslab < ktn ? kt0 + p.kslab : ktn;
+        RowStager as, bs;
+        as.base = p.a + b * p.sa + (long long)m0 * p.lda;
+        as.ld = p.lda;
+        as.rows = p.M - m0;
+        as.kvalid = p.K;
+        bs.base = p.b + b * p.sb + (long long)n0 * p.ldb;
+        bs.ld = p.ldb;
+        bs.rows = p.N - n0;
+        bs.kvalid = p.K;
+        x3_tile<X3_DB, RowStager, RowStager, 2>(as, bs, kt0, kt1, p.M - m0, p.N - n0, p.c + (long long)m0 * p.ldc + n0, p.ldc, lds_x3);
+    } else {
+        RowStager as;
+        as.base = p.a + (long long)m0 * p.lda;
+        as.ld = p.lda;
+        as.rows = p.M - m0;
+        as.kvalid = (p.K + 3) / 4 * 4;         // whole 16-byte groups: the caller pads the rows of A with zeros
+        TransStager bs;
+        bs.base = p.b + t.batch * p.sb + n0;
+        bs.ldk = p.ldb;
+        bs.k_lo = 0;
+        bs.k_hi = p.K;
+        bs.cvalid = p.N - n0;
+        x3_tile<X3_DB, RowStager, TransStager, MODE>(as, bs, 0, (p.K + XK - 1) / XK, p.M - m0, p.N - n0,
+                                                     p.c + t.batch * p.sc + (long long)m0 * p.ldc + n0, p.ldc, lds_x3);
+    }
+}
+}  // namespace
+
+extern "C" int mk_conv1x1_x3(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K,
+                             long long N, int batch, long long sa, long long sb, long long sc, int mode, void* stream) {
+    MK_REQUIRE(a && b && c, "null pointer");
+    MK_REQUIRE(M > 0 && K > 0 && N > 0 && batch > 0, "bad sizes");
+    MK_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (store), 1 (accumulate) or 2 (weight gradient)");
+    MK_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0, "operands must be 16-byte aligned");
+    ConvX3Params p;
+    p.a = a; p.b = b; p.c = c;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.sa = sa; p.sb = sb; p.sc = sc;
+    p.M = M; p.K = K;
+    MK_REQUIRE(N < 2147483647LL, "N too large");
+    p.N = (int)N;
+    p.tiles_m = mk::ceil_div(M, XM);
+    p.tiles_n = mk::ceil_div((int)N, XN);
+    p.nslab = 1;
+    p.kslab = 0;
+    if (mode == 2) {
+        // A [M][K], B [N][K]: rows start on 16-byte boundaries, whole 4-element groups
+        MK_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && K % 4 == 0 && sa % 4 == 0 && sb % 4 == 0, "weight gradient: row strides and the contraction length must be multiples of 4");
+        const int ktn = mk::ceil_div(K, XK);
+        // enough workgroups to fill the chip: ~6 per CU
+        long long want = 1536 / ((long long)p.tiles_m * p.tiles_n * batch);
+        if (want < 1) want = 1;
+        if (want > ktn) want = ktn;
+        p.kslab = mk::ceil_div(ktn, (int)want);
+        p.nslab = mk::ceil_div(ktn, p.kslab);
+        p.nwork = batch * p.nslab;
+    } else {
+        MK_REQUIRE(lda % 4 == 0 && lda >= (K + 3) / 4 * 4, "A: the row stride must be a multiple of 4 and cover K rounded up to 4 (zero padded)");
+        MK_REQUIRE(N % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && sb % 2 == 0 && sc % 2 == 0, "B / C: even row lengths and strides");
+        MK_REQUIRE(33LL * ldb * 4 < (1LL << 31), "B row stride too large for the 32-bit offsets of one k-step");
+        p.nwork = batch;
+    }
+    const long long nblk = grid_blocks(p.nwork, p.tiles_m, p.tiles_n);
+    MK_REQUIRE(nblk < 2147483647LL, "grid too large");
+    const dim3 grid((unsigned)nblk), blk(XT);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) hipLaunchKernelGGL(conv_x3_kernel<0>, grid, blk, X3_LDS, st, p);
+    else if (mode == 1) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, blk, X3_LDS, st, p);
+    else hipLaunchKernelGGL(conv_x3_kernel<2>, grid, blk, X3_LDS, st, p);
     MK_LAUNCH_CHECK();
     return 0;
 }

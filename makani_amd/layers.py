@@ -14,6 +14,33 @@ import torch.nn.functional as F
 from torch.utils.checkpoint import checkpoint
 
 
+class _X3Conv(torch.autograd.Function):
+    """y[b] = W @ x[b] (+ addend[b], accumulated in place) on fp32 ``[B, C, P]`` fields: forward, data gradient and weight
+    gradient on the bf16x3 MFMA engine of the spectral GEMMs (``mk_conv1x1_x3``: fp32-accurate, hand-written) -- the path of
+    every 1x1 convolution outside bf16 autocast."""
+
+    @staticmethod
+    def forward(ctx, x3, w, addend):
+        from . import ops
+        wf = w.detach().float()
+        ctx.save_for_backward(x3, wf)
+        ctx.cfg = (w.dtype, addend is not None)
+        return ops.conv1x1_x3(wf, x3, out=None if addend is None else addend.detach())
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import ops
+        x3, wf = ctx.saved_tensors
+        wdt, has_addend = ctx.cfg
+        gy = gy.contiguous()
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = ops.conv1x1_x3(wf.t().contiguous(), gy)
+        if ctx.needs_input_grad[1]:
+            gw = ops.conv1x1_x3_wgrad(gy, x3).to(wdt)
+        return gx, gw, (gy if has_addend else None)
+
+
 class _PointwiseConv(torch.autograd.Function):
     """y[b] = W @ x[b] on the NCHW field viewed as [C, H*W]; hand-written backward.
 
@@ -359,7 +386,10 @@ class Conv1x1(nn.Conv2d):
             a3 = None
             if addend is not None:
                 a3 = addend.contiguous().view(B, self.out_channels, H * W).to(x3.dtype)
-            y = _PointwiseConv.apply(x3, self.weight2d(), a3)
+            if ops.conv1x1_x3_supported(x3) and (H * W) % 4 == 0 and os.environ.get("MK_CONV_FP32", "x3") == "x3":
+                y = _X3Conv.apply(x3, self.weight2d(), a3)
+            else:
+                y = _PointwiseConv.apply(x3, self.weight2d(), a3)
         if self.bias is not None and add_bias:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)

@@ -338,6 +338,52 @@ def diag_contract(x, w):
 
 
 # ----------------------------------------------------------------------------
+# 1x1 convolutions on fp32 fields: the bf16x3 engine of the spectral GEMMs (fp32-accurate, no vendor GEMM)
+# ----------------------------------------------------------------------------
+def _pad4(w):
+    """[M, K] fp32 -> contiguous [M, K4] with K4 = K rounded up to 4 (zero columns): 16-byte aligned rows for the row stager."""
+    k4 = (w.shape[1] + 3) // 4 * 4
+    if k4 == w.shape[1] and w.is_contiguous():
+        return w
+    out = w.new_zeros(w.shape[0], k4)
+    out[:, :w.shape[1]].copy_(w)
+    return out
+
+
+def conv1x1_x3_supported(x3):
+    """fp32 ``[B, K, P]`` contiguous field on the GPU with an even pixel count."""
+    return x3.is_cuda and x3.dtype == torch.float32 and x3.dim() == 3 and x3.is_contiguous() and x3.shape[2] % 2 == 0
+
+
+def conv1x1_x3(w, x3, out=None):
+    """y[b] = w @ x3[b] (``out`` given: ``out[b] += w @ x3[b]`` in place): w fp32 ``[M, K]``, x3 fp32 ``[B, K, P]`` (``mk_conv1x1_x3``)."""
+    _need_cuda(w, x3)
+    assert w.dtype == torch.float32 and w.dim() == 2 and conv1x1_x3_supported(x3) and w.shape[1] == x3.shape[1]
+    b, k, p = x3.shape
+    m = w.shape[0]
+    a = _pad4(w)
+    if out is not None:
+        assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (b, m, p)
+    y = out if out is not None else torch.empty(b, m, p, dtype=torch.float32, device=x3.device)
+    _lib.check(_lib.load().mk_conv1x1_x3(a.data_ptr(), a.stride(0), x3.data_ptr(), p, y.data_ptr(), p, m, k, p, b, 0, k * p,
+                                         m * p, 1 if out is not None else 0, _stream()), "mk_conv1x1_x3")
+    return y
+
+
+def conv1x1_x3_wgrad(gy, x3):
+    """gW[o][i] = sum_{b,p} gy[b][o][p] x3[b][i][p] for fp32 fields (P a multiple of 4): fp32 ``[O, I]``."""
+    _need_cuda(gy, x3)
+    assert gy.dtype == torch.float32 and x3.dtype == torch.float32 and gy.is_contiguous() and x3.is_contiguous()
+    b, o, p = gy.shape
+    i = x3.shape[1]
+    assert p % 4 == 0 and x3.shape[0] == b and x3.shape[2] == p
+    gw = torch.zeros(o, i, dtype=torch.float32, device=gy.device)
+    _lib.check(_lib.load().mk_conv1x1_x3(gy.data_ptr(), p, x3.data_ptr(), p, gw.data_ptr(), i, o, p, i, b, o * p, i * p, 0, 2,
+                                         _stream()), "mk_conv1x1_x3")
+    return gw
+
+
+# ----------------------------------------------------------------------------
 # per-step arena of the pointwise stack: every packed weight image in ONE launch, every weight-gradient buffer in ONE fill
 # ----------------------------------------------------------------------------
 _ACTIVE_ARENA = None

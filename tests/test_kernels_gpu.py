@@ -364,6 +364,30 @@ def test_conv1x1_wgrad(dev, B, O, I, P):
     assert rel(gw.cpu().numpy(), want.numpy()) < 2e-6      # exact bf16 products, fp32 accumulation
 
 
+# --------------------------------------------------------------------------- fp32 1x1 convolutions on the bf16x3 engine
+@pytest.mark.parametrize("B,M,K,P", [(1, 384, 73, 4104), (2, 73, 384, 33 * 64), (1, 768, 384, 240 * 480), (3, 5, 7, 24), (1, 384, 768, 16392),
+                                      (1, 200, 130, 2050)])
+def test_conv1x1_x3(dev, B, M, K, P):
+    """mk_conv1x1_x3: forward, in-place accumulation onto an addend, and the weight gradient of a 1x1 convolution on fp32 fields,
+    against float64 (fp32-accurate: six bf16 MFMA products of exact three-way operand splits)."""
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(5)
+    w = torch.randn(M, K, generator=g) / K ** 0.5
+    x = torch.randn(B, K, P, generator=g)
+    add = torch.randn(B, M, P, generator=g)
+    gy = torch.randn(B, M, P, generator=g)
+    want = torch.matmul(w.double(), x.double())
+    y = ops.conv1x1_x3(w.to(dev), x.to(dev))
+    assert rel(y.cpu().numpy(), want.numpy()) < 2e-6
+    out = add.to(dev).clone()
+    y2 = ops.conv1x1_x3(w.to(dev), x.to(dev), out=out)
+    assert y2.data_ptr() == out.data_ptr()
+    assert rel(y2.cpu().numpy(), (want + add.double()).numpy()) < 2e-6
+    if P % 4 == 0:
+        gw = ops.conv1x1_x3_wgrad(gy.to(dev), x.to(dev))
+        assert rel(gw.cpu().numpy(), torch.einsum("bop,bip->oi", gy.double(), x.double()).numpy()) < 2e-6
+
+
 # --------------------------------------------------------------------------- diagonal filter contraction
 @pytest.mark.parametrize("B,I,O,L,M", [(2, 6, 5, 7, 8), (5, 3, 9, 16, 17), (1, 32, 32, 30, 31)])
 def test_diag_contract_fwd_bwd(dev, B, I, O, L, M):
