@@ -111,6 +111,11 @@ __global__ __launch_bounds__(WT) void conv1x1_wgrad_kernel(WgradParams p) {
         for (int c = 0; c < 2; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+    // accumulators in the AccVGPR half of the register file (AGPR form of the MFMAs): see x3_tile in gemm_x3.hip
+#pragma unroll
+    for (int a = 0; a < MT; ++a)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) asm volatile("" : "+a"(acc[a][c]));
 
     // Register ring RD k-steps deep: one k-step of MFMAs is only 16 x 32 = 512 cycles, far less than a load's flight
     // time, so the loads of k-step kt + 1 + RD are issued when the registers of k-step kt + 1 have been written to LDS.
@@ -253,6 +258,10 @@ __global__ __launch_bounds__(WT8) void conv1x1_wgrad_big_kernel(WgradParams p) {
         for (int c = 0; c < CT; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][c][r] = 0.f;
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) asm volatile("" : "+a"(acc[a][c]));      // AGPR form of the MFMAs: see x3_tile in gemm_x3.hip
 
     uint4 ra[NVA], rb[NVB];
     const int nk = (int)((k_end - k_begin + 63) / 64);

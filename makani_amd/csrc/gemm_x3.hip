@@ -324,18 +324,43 @@ __device__ __forceinline__ void x3_mfma_step(const char* As, const char* Bs, con
 #pragma unroll
         for (int b = 0; b < 2; ++b)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) bf[b][p] = *reinterpret_cast<const bf16x8*>(Bs + b_off[b] + p * 64 + s * 32);
+            for (int p = 0; p < 3; ++p) {
+#if defined(MK_X3_NOREAD)      // experiment: operands from registers, no LDS traffic in the step
+                typedef int x3_i4 __attribute__((ext_vector_type(4)));
+                x3_i4 fake = {b_off[b] + p, s, b, p};
+                asm volatile("" : "+v"(fake));
+                bf[b][p] = __builtin_bit_cast(bf16x8, fake);
+#else
+                bf[b][p] = *reinterpret_cast<const bf16x8*>(Bs + b_off[b] + p * 64 + s * 32);
+#endif
+            }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
             if (live[a]) {
                 bf16x8 af[3];
 #pragma unroll
-                for (int p = 0; p < 3; ++p) af[p] = *reinterpret_cast<const bf16x8*>(As + a_off[a] + p * 64 + s * 32);
+                for (int p = 0; p < 3; ++p) {
+#if defined(MK_X3_NOREAD)
+                    typedef int x3_i4 __attribute__((ext_vector_type(4)));
+                    x3_i4 fake = {a_off[a] + p, s, a, p};
+                    asm volatile("" : "+v"(fake));
+                    af[p] = __builtin_bit_cast(bf16x8, fake);
+#else
+                    af[p] = *reinterpret_cast<const bf16x8*>(As + a_off[a] + p * 64 + s * 32);
+#endif
+                }
 #pragma unroll
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
-                    for (int b = 0; b < 2; ++b)
+                    for (int b = 0; b < 2; ++b) {
+#if defined(MK_X3_NOMFMA)      // experiment: the LDS reads stay, the matrix instruction becomes one VALU op
+                        acc[a][b][t] += __builtin_bit_cast(float4, af[PA[t]]).x * __builtin_bit_cast(float4, bf[b][PB[t]]).y;
+#elif defined(MK_X3_AGPR)      // experiment: accumulators in the AccVGPR half of the register file
+                        asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(acc[a][b]) : "v"(af[PA[t]]), "v"(bf[b][PB[t]]));
+#else
                         acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[PA[t]], bf[b][PB[t]], acc[a][b], 0, 0, 0);
+#endif
+                    }
             }
     }
 }
@@ -367,6 +392,14 @@ __device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    // The accumulators live in the AccVGPR half of the register file (the empty asm makes the compiler select the AGPR form
+    // of the MFMAs, as the vendor GEMM libraries do).  With arch-VGPR accumulators this kernel corrupted LDS-exchange kernels
+    // that shared its CUs -- rocFFT's and this package's FFT rows, 16 lanes x one register at a time -- whenever another stream
+    // or another process ran them at the same moment (tools/ab/share_stress.py torch_fft@mk_dhconv: 300 of 300 rocFFT results
+    // wrong next to the VGPR form, 0 of 300 next to this one; profiles/r03_share_stress.txt).
+#if !defined(MK_X3_VGPR_ACC)
+    asm volatile("" : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[1][0]), "+a"(acc[1][1]));
+#endif
 
     bool live[2];
     int a_off[2], b_off[2];

@@ -8,6 +8,12 @@ issues the same collectives in the same order on each communicator, the streams 
 micro-batch, so the transposes of micro-batch 0 overlap the FFT / Legendre / GEMM kernels of micro-batch 1 and vice
 versa, forward and backward (autograd replays every node on the stream, and here the lane, of its forward).
 
+CAUTION (round 3): kernels of two streams that run at the same moment are NOT independent on the MI355X boxes this was built
+on -- a dense bf16-MFMA workgroup (dhconv, weight gradients) beside an LDS-exchange workgroup (the FFT rows; rocFFT's just the
+same) leaves single 16-lane register beats of the latter stale, a handful of wrong rows per hundred launches
+(tools/ab/share_stress.py, profiles/r03_share_stress.txt).  The runner is therefore opt-in
+(``MK_BENCH_MICROBATCH=2`` in bench.py); the default step keeps one stream.
+
 The reference has no counterpart (its trainer runs one stream, makani/utils/trainer.py:742-763); results are identical
 to the single-stream step up to the fp32 order of the gradient accumulation over the micro-batches.
 """

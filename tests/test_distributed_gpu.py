@@ -362,13 +362,39 @@ def _body_net_prod(dev):
     assert err < 2e-5, f"rank {hr}: output error {err:.3e}"
 
 
-def _worker(rank, world, port, what, q):
+def _take_turns_on_the_card(lock):
+    """The ranks of these tests share ONE card, which production never does (one process per GPU).  Kernels of different
+    processes (or streams) that run at the same moment are not independent on this hardware: a workgroup of dense bf16 MFMAs
+    beside an LDS-exchange kernel (the FFT rows here; rocFFT's just the same) leaves single 16-lane register beats of the
+    latter stale -- tools/ab/share_stress.py, DESIGN.md section 7.4.  So a rank computes only while it holds ``lock`` and hands
+    it over, with its stream drained, around every collective: what the test then exercises is what production runs, a
+    rank's kernels alone on its card, with gloo in place of RCCL on the wire."""
+    def wrap(fn):
+        def call(*args, **kwargs):
+            torch.cuda.synchronize()
+            lock.release()
+            try:
+                return fn(*args, **kwargs)
+            finally:
+                torch.cuda.synchronize()          # gloo's device copies
+                lock.acquire()
+        return call
+    for name in ("all_to_all_single", "all_reduce", "all_gather", "broadcast", "barrier", "all_to_all", "reduce_scatter_tensor",
+                 "all_gather_into_tensor", "new_group", "all_gather_object", "broadcast_object_list", "reduce"):   # every blocking call
+        setattr(dist, name, wrap(getattr(dist, name)))
+
+
+def _worker(rank, world, port, what, q, lock):
+    held = False
     try:
         os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                           LOCAL_RANK="0")
         from makani_amd import comm
         comm.init(model_parallel_sizes=[1, world, 1, 1] if what.endswith("_w") else [world, 1, 1, 1], backend="gloo")
         dev = torch.device("cuda:0")
+        _take_turns_on_the_card(lock)
+        lock.acquire()
+        held = True
         globals()["_body_" + what](dev)
         torch.cuda.synchronize()
         dist.barrier()
@@ -377,6 +403,11 @@ def _worker(rank, world, port, what, q):
         import traceback
         q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
     finally:
+        if held:
+            try:
+                lock.release()
+            except ValueError:
+                pass
         if dist.is_initialized():
             dist.destroy_process_group()
 
@@ -387,7 +418,8 @@ def test_h2_on_one_gpu(what):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, what, q)) for r in range(2)]
+    lock = ctx.Lock()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, what, q, lock)) for r in range(2)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]
@@ -404,7 +436,8 @@ def test_h4_production_shards_on_one_gpu(what):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 4, port, what, q)) for r in range(4)]
+    lock = ctx.Lock()
+    procs = [ctx.Process(target=_worker, args=(r, 4, port, what, q, lock)) for r in range(4)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in procs]

@@ -15,7 +15,8 @@ RUNS = int(os.environ.get("RUNS", "6"))
 def worker(rank, world, port, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     from makani_amd import comm
-    comm.init(model_parallel_sizes=[world, 1, 1, 1], backend="gloo")
+    solo = os.environ.get("SOLO", "0") == "1"           # ranks share the card but not the model: no collective in the forward
+    comm.init(model_parallel_sizes=[1 if solo else world, 1, 1, 1], backend="gloo")
     import bench
     from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
     from makani_amd.distributed import split_tensor_along_dim
@@ -23,7 +24,7 @@ def worker(rank, world, port, q):
     torch.manual_seed(333)
     net = SphericalFourierNeuralOperatorNet(**bench.CONFIG).to(dev)
     xg = torch.randn(1, 73, 721, 1440)
-    xl = split_tensor_along_dim(xg, 2, world)[rank].contiguous().to(dev)
+    xl = (xg if solo else split_tensor_along_dim(xg, 2, world)[rank].contiguous()).to(dev)
     names, diffs, ref, where = [], [], {}, []
     state = {"run": 0}
     keep = os.environ.get("KEEP", "encoder,blocks.0,blocks.1").split(",")
