@@ -334,8 +334,22 @@ def _body_ckpt(rank, world):
     with pytest.raises(NotImplementedError):
         checkpoint.restore_flexible_checkpoint(path, net, load_optimizer=True)
     dist.barrier()
+    # a file whose ``params`` entry holds a pickled class (the reference stores its YParams object there) is refused by the
+    # default loader (weights_only) and read only when the caller vouches for it
+    import argparse
+    import pickle
+    path2 = path.replace("mk_flex_", "mk_flex2_")
+    if rank == 0:
+        stored["params"] = argparse.Namespace(nettype="sfno")
+        torch.save(stored, path2.format(mp_rank=0))
+    dist.barrier()
+    with pytest.raises(pickle.UnpicklingError):
+        checkpoint.restore_flexible_checkpoint(path2, net)
+    assert checkpoint.restore_flexible_checkpoint(path2, net, trusted_pickle=True) == (7, 3)
+    dist.barrier()
     if rank == 0:
         os.remove(path.format(mp_rank=0))
+        os.remove(path2.format(mp_rank=0))
 
 
 def _body_fft2(rank, world):

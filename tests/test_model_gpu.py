@@ -382,3 +382,117 @@ def test_microbatch_runner_matches_single_stream(dev):
         for n, p in net.named_parameters():
             if n in g_ref:
                 assert rel(p.grad, g_ref[n], floor=0.1 * scale) < 2e-5, n
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Review items of round 2: each fix has its test
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cin,cout,on_engine", [(768, 1536, True), (512, 2048, False), (1536, 768, True)])
+def test_conv1x1_wide_layers_train_or_fall_back(dev, cin, cout, on_engine):
+    """the engine was chosen from the forward shape alone; the data gradient packs the TRANSPOSED GEMM
+    (K' = out_channels) and a 768 -> 1536 layer (`sfno_dhealy_73ch_edim768`, icml_models.yaml:277) raised in backward, a 2048-row
+    layer already in forward.  `ops.pce_supported_train` checks both orientations and the four-pass limit: wide layers train
+    on the engine where both GEMMs fit and fall back where one does not -- forward, input gradient and weight gradient against
+    the fp32 convolution."""
+    from makani_amd import ops
+    from makani_amd.layers import Conv1x1
+    assert ops.pce_supported_train(cout, cin) == on_engine
+    torch.manual_seed(5)
+    conv = Conv1x1(cin, cout, bias=True).to(dev)
+    x = torch.randn(1, cin, 24, 40, device=dev, requires_grad=True)
+    g = torch.randn(1, cout, 24, 40, device=dev)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        y = conv(x)
+    y.float().backward(g)
+    xr = x.detach().clone().requires_grad_(True)
+    wr = conv.weight.detach().clone().requires_grad_(True)
+    yr = torch.nn.functional.conv2d(xr, wr, conv.bias.detach())
+    gx_ref, gw_ref = torch.autograd.grad(yr, (xr, wr), g)
+    assert rel(y, yr) < 1e-2
+    assert rel(x.grad, gx_ref) < 1.5e-2
+    assert rel(conv.weight.grad, gw_ref) < 1.5e-2
+
+
+def test_legendre_operand_past_2_gib(dev):
+    """the branch-free stagers addressed the k-major operand through ONE buffer descriptor with 32-bit byte
+    offsets spanning the whole tensor; past 2 GiB in-range lanes read zeros without an error.  The descriptor is rebased per
+    k-step now.  A latitude-major operand of 2.4 GiB: the spectrum at the last channels and modes (whose rows lie past 2^31 bytes
+    from the base) against the float64 contraction."""
+    from makani_amd import ops
+    K, L, M, BC = 96, 48, 49, 65536
+    assert K * M * BC * 8 > 2 ** 31
+    tab = ops.legendre_table("legendre-gauss", K, L, M, True).to(dev)
+    xf = torch.empty(K, M, BC, dtype=torch.complex64, device=dev)
+    g = torch.Generator(device=dev).manual_seed(3)
+    torch.view_as_real(xf).normal_(generator=g)
+    c = ops.legendre_fwd_raw(xf, tab, L, 0, None, True)              # [L, M, BC]
+    for m in (0, 17, 48):
+        for ch in (slice(0, 64), slice(BC - 64, BC)):
+            want = torch.einsum("lk,kc->lc", tab[m, :, :K].double().to(torch.complex128), xf[:, m, ch].to(torch.complex128))
+            got = c[m:, m, ch]
+            assert rel(got, want[m:]) < 1e-5, (m, ch)
+    # and back: synthesis reads the 2.4 GiB spectrum-side operand the same way
+    tabi = ops.legendre_table("legendre-gauss", K, L, M, False).to(dev)
+    big = torch.zeros(L, M, BC, dtype=torch.complex64, device=dev)
+    big.copy_(c)
+    l = torch.arange(L, device=dev).view(-1, 1, 1)
+    mm = torch.arange(M, device=dev).view(1, -1, 1)
+    big = torch.where(l >= mm, big, torch.zeros((), dtype=big.dtype, device=dev))
+    y = ops.legendre_inv_raw(big, tabi, K, 0, None, True)            # [K, M, BC]
+    for m in (0, 48):
+        ch = slice(BC - 64, BC)
+        want = torch.einsum("lk,lc->kc", tabi[m, :, :K].double().to(torch.complex128), big[:, m, ch].to(torch.complex128))
+        assert rel(y[:, m, ch], want) < 1e-5, m
+
+
+def test_hip_graph_capture_after_one_warmup(dev):
+    """the first cache hit of a Legendre tile image queried its build event -- illegal inside a capture.  With
+    ONE warm-up iteration the first hit after the build lies inside the capture (the three warm-ups of the test above hid it)."""
+    import gc
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    torch.manual_seed(7)
+    kw = dict(inp_shape=(32, 64), out_shape=(32, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=8, num_layers=2)
+    net = SphericalFourierNeuralOperatorNet(**kw).to(dev)
+    x = torch.randn(2, 4, 32, 64, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.no_grad():
+            ref = net(x).clone()                             # the one warm-up: builds the images, records their events
+        gc.collect()
+        graph = torch.cuda.CUDAGraph()
+        graph.capture_begin()
+        with torch.no_grad():
+            out = net(x)
+        graph.capture_end()
+    torch.cuda.current_stream().wait_stream(s)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+
+
+def test_fused_adam_state_dict_round_trip_and_foreign_layout(dev):
+    """a state dict of another layout (plain torch Adam) must be refused, not ignored; lr changes made on
+    ``param_groups`` must reach the large-tensor pass; the own layout restores bit-exactly."""
+    from makani_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    big = torch.nn.Parameter(torch.randn(1 << 21, device=dev))            # the large-tensor path
+    small = torch.nn.Parameter(torch.randn(64, device=dev))
+    opt = FusedAdam([big, small], lr=1e-3)
+    for _ in range(2):
+        big.grad, small.grad = torch.randn_like(big), torch.randn_like(small)
+        opt.step()
+    sd = opt.state_dict()
+    with pytest.raises(ValueError):
+        opt.load_state_dict(torch.optim.Adam([torch.nn.Parameter(torch.zeros(3))]).state_dict())
+    assert opt.param_groups is opt.param_groups                            # ONE persistent list: a scheduler's change sticks
+    for gr in opt.param_groups:
+        gr["lr"] = 0.0                                                     # ... and reaches both passes
+    before = (big.detach().clone(), small.detach().clone())
+    big.grad, small.grad = torch.randn_like(big), torch.randn_like(small)
+    opt.step()
+    assert torch.equal(big, before[0]) and torch.equal(small, before[1])
+    opt2 = FusedAdam([big, small], lr=1e-3)
+    opt2.load_state_dict(sd)
+    for a, b in zip(opt2.state_dict()["big"], sd["big"]):
+        assert torch.equal(a["m"], b["m"]) and torch.equal(a["v"], b["v"]) and a["step"] == b["step"]

@@ -283,3 +283,25 @@ def test_geometric_h1_loss(dev, absolute, squared):
     want = ol.geometric_h1_loss(sht(prd - tar).numpy(), None if absolute else sht(tar).numpy(), squared=squared)
     assert abs(float(out.detach()) - want) < 2e-5 * abs(want)
     assert torch.isfinite(pd.grad).all() and pd.grad.abs().sum() > 0
+
+
+def test_loss_handler_geometric_h1_any_batch(dev):
+    """``LossHandler`` handed the per-channel weights ``[1, C]`` to the H1 loss as its per-SAMPLE mask, which
+    broadcasts only for B == 1 or B == C.  B = 3, C = 4: the handler's value equals the loss object's own (no mask), gradient
+    finite.  (The reference cannot reach this branch -- losses.py:129-130 -- so there is no reference value: parity unpinned.)"""
+    from types import SimpleNamespace
+    from makani_amd.losses import GeometricH1Loss, LossHandler
+    H, W, C, B = 33, 64, 4, 3
+    params = SimpleNamespace(loss="relative geometric h1", n_future=0, img_shape_x=H, img_shape_y=W, img_crop_shape_x=H,
+                             img_crop_shape_y=W, img_crop_offset_x=0, img_crop_offset_y=0, N_out_channels=C,
+                             channel_names=["u10m", "sst", "t2m", "z500"], channel_weights="auto", model_grid_type="equiangular")
+    torch.manual_seed(8)
+    h = LossHandler(params).to(dev)
+    h.train()
+    prd = torch.randn(B, C, H, W, device=dev, requires_grad=True)
+    tar = torch.randn(B, C, H, W, device=dev)
+    out = h(prd, tar, None)
+    out.backward()
+    want = GeometricH1Loss((H, W), absolute=False, squared=False).to(dev)(prd.detach(), tar)
+    assert out.dim() == 0 and abs(float(out) - float(want)) <= 1e-6 * abs(float(want))
+    assert torch.isfinite(prd.grad).all() and prd.grad.abs().sum() > 0
