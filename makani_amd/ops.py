@@ -175,9 +175,10 @@ def legendre_x3_image(table, nlat, inverse):
         return img
     if entry[1] is not None:
         if torch.cuda.is_current_stream_capturing():
-            # an event query is illegal inside a stream capture; ordering behind the build is harmless (and a no-op
-            # once the build has finished)
-            torch.cuda.current_stream().wait_event(entry[1])
+            # inside a stream capture the event may neither be queried nor waited for (it belongs to uncaptured work:
+            # hipErrorStreamCaptureIsolation).  Nothing to do: the build was issued before the capture began, either on this
+            # stream (ordered before every replay) or on one the caller has joined before capturing, as for any other input
+            return entry[0]
         elif entry[1].query():
             entry[1] = None                     # built and finished: nothing to order any more
         else:
