@@ -138,6 +138,15 @@ int mk_rfft_pm(const void* x, int x_dtype, float* xf, const float* twiddles, int
 int mk_irfft_pm(const float* xf, void* x, int x_dtype, const float* twiddles, int bc, int nlat, int nlon, int mmax,
                 float scale0, float scale_m, float scale_h, int chans, int chans_per_peer, void* stream);
 
+/* Inverse transform that also delivers the statistics of its output (round 3): rowsums[2 r], rowsums[2 r + 1] += sum and sum of
+ * squares of output row r (= b * C + c) over this call's latitudes, on the values as stored; fp64 accumulators zeroed by the
+ * caller.  It is the statistics pass of the instance norm that follows the inverse SHT in every FNO block
+ * (sfnonet.py:239-253: norm0) without a second read of the field.  chans_per_peer > 0: peer-major rows as mk_irfft_pm, else
+ * xf_layout as mk_irfft_ex.  Production lengths only (nlon 480 / 1440, mmax <= 241). */
+int mk_irfft_sums(const float* xf, void* x, int x_dtype, const float* twiddles, int bc, int nlat, int nlon, int mmax,
+                  float scale0, float scale_m, float scale_h, int xf_layout, int chans, int chans_per_peer, double* rowsums,
+                  void* stream);
+
 /* ---- spectral filter contraction (K5) ---------------------------------- */
 /* y[l][m][b][o] = sum_i x[l][m][b][i] * w[l][i][o]  (complex), for global m <= l.
  * Replaces _contract_dhconv `einsum("bixy,iox->boxy")` (contractions.py:130-136,

@@ -40,6 +40,8 @@ SIGNATURES = {
     "mk_irfft_ex": (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _vp]),
     "mk_rfft_pm": (_c_int, [_vp, _c_int, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _c_int, _vp]),
     "mk_irfft_pm": (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _c_int, _vp]),
+    "mk_irfft_sums": (_c_int, [_vp, _vp, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_float, _c_float, _c_float, _c_int, _c_int,
+                               _c_int, _vp, _vp]),
     "mk_legendre_fwd_x3_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_legendre_inv_x3_ex": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp]),
     "mk_dhconv_fwd": (_c_int, [_vp, _vp, _vp] + [_c_int] * 7 + [_vp]),

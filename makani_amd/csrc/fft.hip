@@ -32,6 +32,7 @@ struct XfLayout {
     long long pstride;    // K * M * Bn * Cp
 };
 static thread_local XfLayout g_xl = {0, 0, 0, 0, 0, 0};   // set by the C entry points before they launch
+static thread_local double* g_rowsums = nullptr;          // mk_irfft_sums: per-row (sum, sum of squares) accumulators of the output
 
 // per-tile channel addressing: all G rows of a split-kernel tile lie in one (batch item, channel block) when Cp % G == 0
 struct XfChan {
@@ -612,4 +613,22 @@ extern "C" int mk_irfft_pm(const float* xf, void* x, int x_dtype, const float* t
         launch_irfft_split<3>(xf, x, x_dtype, twiddles, bc, nlat, mmax, scale0, scale_m, scale_h, (hipStream_t)stream);
     MK_LAUNCH_CHECK();
     return 0;
+}
+
+// Inverse transform that also delivers the statistics of its output: rowsums[2 r], rowsums[2 r + 1] += sum / sum of squares of
+// output row r = b * C + c over this call's latitudes and all longitudes (fp64 accumulators the caller has zeroed), taken on
+// the values as stored -- the first pass of the instance norm that follows the inverse SHT in every block (sfnonet.py:239-253)
+// without reading the field again.  Split kernels only (nlon 480 / 1440, mmax <= 241); chans_per_peer > 0 selects the peer-major
+// layout of mk_irfft_pm, else xf_layout as in mk_irfft_ex.
+extern "C" int mk_irfft_sums(const float* xf, void* x, int x_dtype, const float* twiddles, int bc, int nlat, int nlon, int mmax,
+                             float scale0, float scale_m, float scale_h, int xf_layout, int chans, int chans_per_peer,
+                             double* rowsums, void* stream) {
+    MK_REQUIRE(rowsums != nullptr, "null pointer");
+    MK_REQUIRE(!fft_legacy() && mmax <= 241 && (nlon == 480 || nlon == 1440), "row statistics come from the split kernels only");
+    g_rowsums = rowsums;
+    const int rc = chans_per_peer > 0
+        ? mk_irfft_pm(xf, x, x_dtype, twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, chans, chans_per_peer, stream)
+        : mk_irfft_ex(xf, x, x_dtype, twiddles, bc, nlat, nlon, mmax, scale0, scale_m, scale_h, xf_layout, stream);
+    g_rowsums = nullptr;
+    return rc;
 }

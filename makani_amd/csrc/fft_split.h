@@ -39,8 +39,17 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
-// radix-16 then radix-15 on the sub-row owned by this lane group; tw15[r] = exp(-2 pi i k r / 240)
-__device__ __forceinline__ void split_passes(float2* lds, int tid, int S, const float2 (&tw15)[15]) {
+// value of an output element as it is stored (fp32 rows: itself; bf16 rows: rounded): what the statistics below must see
+template <typename T> __device__ __forceinline__ float as_stored(float v);
+template <> __device__ __forceinline__ float as_stored<float>(float v) { return v; }
+template <> __device__ __forceinline__ float as_stored<__hip_bfloat16>(float v) { return __bfloat162float(__float2bfloat16(v)); }
+
+// radix-16 then radix-15 on the sub-row owned by this lane group; tw15[r] = exp(-2 pi i k r / 240).
+// SUMS (inverse transform only): the finished sub-row IS 480 consecutive-stride output reals (x[2n] = Re z, x[2n+1] = -Im z);
+// their sum and sum of squares, taken on the values as stored, go to red[2 sr], red[2 sr + 1] -- the row statistics of the
+// instance norm that reads the field next, for free while the row is in registers.
+template <bool SUMS = false, typename TOut = float>
+__device__ __forceinline__ void split_passes(float2* lds, int tid, int S, const float2 (&tw15)[15], float* red = nullptr) {
     const int sr = tid >> 4, j = tid & 15;
     float2* base = lds + sub_base(sr, S);
     if (j < 15) {
@@ -60,6 +69,24 @@ __device__ __forceinline__ void split_passes(float2* lds, int tid, int S, const 
     Dft<15>::run(u);
 #pragma unroll
     for (int r = 0; r < 15; ++r) base[j + 17 * r] = u[r];
+    if constexpr (SUMS) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 15; ++r) {
+            const float a = as_stored<TOut>(u[r].x), b = as_stored<TOut>(u[r].y);
+            s1 += a - b;
+            s2 = fmaf(a, a, fmaf(b, b, s2));
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {      // the 16 lanes of the sub-row
+            s1 += __shfl_xor(s1, o, 16);
+            s2 += __shfl_xor(s2, o, 16);
+        }
+        if (j == 0 && red != nullptr) {
+            red[2 * sr] = s1;
+            red[2 * sr + 1] = s2;
+        }
+    }
 }
 
 template <typename T> struct InVec;
@@ -256,9 +283,11 @@ template <> struct OutVec<__hip_bfloat16> {
 template <int S, typename TOut, bool WIDE, int PERSIST>
 __global__ __launch_bounds__(STHREADS, PERSIST ? 3 : 5) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
-                                                               float scale0, float scale_m, float scale_h, XfLayout xl) {
+                                                               float scale0, float scale_m, float scale_h, XfLayout xl,
+                                                               double* __restrict__ rowsums) {
     constexpr int N = 480 * S, G = SNSUB / S, HH = N / 2;
     extern __shared__ __attribute__((aligned(16))) float2 lds[];
+    float* red = reinterpret_cast<float*>(lds + SLDS_F2);      // [24 sub-rows][sum, sum of squares] (rowsums only)
     const int tid = threadIdx.x;
     const int ntile = (BC + G - 1) / G;
     const int total = ntile * K;
@@ -381,8 +410,18 @@ __global__ __launch_bounds__(STHREADS, PERSIST ? 3 : 5) void irfft_split_kernel(
     __syncthreads();
     const int next = PERSIST ? next_valid(sched + (int)gridDim.x) : total16;
     if (next < total16) gather(pair_tile(next), opaque(tid));
-    split_passes(lds, tl, S, tw15);
+    if (rowsums != nullptr) split_passes<true, TOut>(lds, tl, S, tw15, red);
+    else split_passes(lds, tl, S, tw15);
     __syncthreads();
+    if (rowsums != nullptr && tl < 2 * G) {      // one fp64 atomic per (channel, statistic) and tile: the row's share of the field sums
+        const int gch = tl >> 1, t = tl & 1;
+        if (bc0 + gch < BC) {
+            float v = 0.f;
+#pragma unroll
+            for (int sq = 0; sq < S; ++sq) v += red[2 * (gch * S + sq) + t];
+            atomicAdd(&rowsums[2 * (size_t)(bc0 + gch) + t], (double)v);
+        }
+    }
 
     // copy-out: groups of EO*S reals = EO reals (EO/2 complex, contiguous in the padded image) of every
     // sub-sequence, de-conjugated; EO = 4 (fp32 rows) or 8 (bf16 rows) -> 16-byte stores
@@ -459,13 +498,13 @@ int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, i
                        float sm, float sh, hipStream_t st) {
     constexpr int G = SNSUB / S;
     const dim3 grid(split_grid(mk::ceil_div(bc, G) * (long long)nlat));
-    const size_t lds = sizeof(float2) * SLDS_F2;
+    const size_t lds = sizeof(float2) * SLDS_F2 + 2 * SNSUB * sizeof(float);
     // 32-bit mode offsets inside a tile's buffer descriptor: (240 modes + one row of channels) * 8 bytes must stay below 2^31
     const long long bcx = g_xl.Cp ? (long long)g_xl.Bn * g_xl.Cp : (long long)bc;
     const bool wide = ((long long)SH * g_xl.sm + 1) * bcx * 8 >= (1LL << 31);
 #define MK_IRFFT_LAUNCH(T, W, PS)                                                                                      \
     hipLaunchKernelGGL((irfft_split_kernel<S, T, W, PS>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,        \
-                       (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl)
+                       (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl, g_rowsums)
     if (x_dtype == 0) {
         if (wide) MK_IRFFT_LAUNCH(float, true, 1); else MK_IRFFT_LAUNCH(float, false, 0);
     } else {

@@ -221,8 +221,15 @@ class DistributedInverseRealSHT(_DistSHTBase):
         super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
         self.register_buffer("pct", ops.legendre_table(grid, nlat, self.lmax, self.mmax, False), persistent=False)
 
-    def inverse_packed(self, c, B, out_dtype=torch.float32):
-        """spectrum [l_loc, m_loc, B*C] -> x [B, C, nlat_loc, nlon_loc]."""
+    def inverse_packed(self, c, B, out_dtype=torch.float32, want_row_sums=False):
+        """spectrum [l_loc, m_loc, B*C] -> x [B, C, nlat_loc, nlon_loc]; ``want_row_sums``: (x, LOCAL fp64 ``[B*C, 2]`` row sums of x
+        or None where the path has no kernel for them) -- the sharded instance norm all-reduces them (layer_norm.py)."""
+        if want_row_sums:
+            x = self._inverse_packed(c, B, out_dtype, True)
+            return x if isinstance(x, tuple) else (x, None)
+        return self._inverse_packed(c, B, out_dtype, False)
+
+    def _inverse_packed(self, c, B, out_dtype, want_row_sums):
         C = c.shape[2] // B
         c = c.view(c.shape[0], c.shape[1], B, C)
         if self.comm_size_azimuth == 1 and self.comm_size_polar > 1 and ops.SPECTRAL_GEMM == "bf16x3":
@@ -236,6 +243,9 @@ class DistributedInverseRealSHT(_DistSHTBase):
                 # the latitude chunks are sent as they lie; the received buffer [h, K_loc, M, B, C/h] is read peer-major
                 kl, unit = self.nlat_local, self.mmax * B * Ch
                 xf = _AllToAllFlat.apply(xf, [k * unit for k in self.lat_shapes], [kl * unit] * h, comm.get_group("h"))
+                if want_row_sums and ops.irfft_sums_supported(self.nlon, self.mmax) and out_dtype in (torch.float32, torch.bfloat16):
+                    x, sums = ops.irfft_pm(xf.view(h, kl, self.mmax, B * Ch), self.twiddles, self.nlon, out_dtype, C, Ch, True)
+                    return x.view(B, C, -1, self.nlon), sums
                 x = ops.irfft_pm(xf.view(h, kl, self.mmax, B * Ch), self.twiddles, self.nlon, out_dtype, C, Ch)
                 return x.view(B, C, -1, self.nlon)
             xf = distributed_transpose_polar.apply(xf, (0, 3), compute_split_shapes(C, self.comm_size_polar))

@@ -84,3 +84,25 @@ class DistributedInstanceNorm2d(nn.Module):
         if self.affine:
             x = self.weight.reshape(-1, 1, 1) * x + self.bias.reshape(-1, 1, 1)
         return x
+
+
+class DistributedLayerNorm(nn.Module):
+    """``makani/mpu/layer_norm.py:117-155``: layer norm over the CHANNEL axis of an NCHW field, per grid point (so it needs no
+    communication under spatial sharding; the reference notes that it breaks equivariance).  Same parameters
+    (``norm.weight`` / ``norm.bias``, shared over the ``model`` group) and the same arithmetic: transpose channels last,
+    ``nn.LayerNorm``, transpose back.  Outside the benchmarked configuration (instance norm): torch ops, no HIP kernel."""
+
+    def __init__(self, normalized_shape, eps=1e-05, elementwise_affine=True, bias=True, device=None, dtype=None):
+        super().__init__()
+        assert comm.get_size("matmul") == 1
+        self.norm = nn.LayerNorm(normalized_shape, eps=eps, elementwise_affine=elementwise_affine, bias=bias, device=device,
+                                 dtype=dtype)
+        if elementwise_affine:
+            self.norm.weight.is_shared_mp = ["model"]
+            self.norm.weight.sharded_dims_mp = [None]
+            if bias:
+                self.norm.bias.is_shared_mp = ["model"]
+                self.norm.bias.sharded_dims_mp = [None]
+
+    def forward(self, x):
+        return torch.transpose(self.norm(torch.transpose(x, 1, 3)), 1, 3).contiguous()

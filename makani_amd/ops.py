@@ -93,6 +93,32 @@ def irfft_bf16_rows(nlon, mmax):
     return nlon in (480, 1440) and mmax <= 241
 
 
+def irfft_sums_supported(nlon, mmax):
+    """The inverse FFT can deliver the row statistics of its output (``mk_irfft_sums``: the split kernels)."""
+    return nlon in (480, 1440) and mmax <= 241 and os.environ.get("MK_FFT_LEGACY", "0") != "1" \
+        and os.environ.get("MK_IRFFT_SUMS", "1") != "0"
+
+
+def irfft_sums_raw(xf, twiddles, nlon, out_dtype, kmajor=False, chans=0, cpp=0):
+    """``irfft`` (scales 1, 1, 1) of plain (``[M, K, BC]`` / ``[K, M, BC]``) or peer-major (``cpp`` > 0:
+    ``[chans / cpp, K, M, B * cpp]``) Fourier rows -> (x ``[BC, K, nlon]``, fp64 ``[BC, 2]`` sums and sums of squares of its rows)."""
+    _need_cuda(xf, twiddles)
+    assert xf.is_contiguous() and xf.dtype == torch.complex64 and out_dtype in (torch.float32, torch.bfloat16)
+    if cpp:
+        p, k, m, bcp = xf.shape
+        bc = (bcp // cpp) * chans
+    elif kmajor:
+        k, m, bc = xf.shape
+    else:
+        m, k, bc = xf.shape
+    x = torch.empty(bc, k, nlon, dtype=out_dtype, device=xf.device)
+    sums = torch.zeros(bc, 2, dtype=torch.float64, device=xf.device)
+    _lib.check(_lib.load().mk_irfft_sums(xf.data_ptr(), x.data_ptr(), 1 if out_dtype == torch.bfloat16 else 0, twiddles.data_ptr(),
+                                         bc, k, nlon, m, 1.0, 1.0, 1.0, int(bool(kmajor)), int(chans), int(cpp), sums.data_ptr(),
+                                         _stream()), "mk_irfft_sums")
+    return x, sums
+
+
 def irfft_raw(xf, twiddles, nlon, s0, sm, sh, out_dtype=torch.float32, kmajor=False):
     """xf complex64 [M, K, BC] ([K, M, BC] with ``kmajor``) -> x [BC, K, nlon] in fp32, or bf16 where the kernel
     fuses the cast."""
@@ -654,18 +680,22 @@ class _IRFFT(torch.autograd.Function):
     """xf [M, K, BC] -> x [BC, K, nlon] = irfft(xf, n=nlon, norm="forward") (K4)."""
 
     @staticmethod
-    def forward(ctx, xf, twiddles, nlon, out_dtype, kmajor=False):
+    def forward(ctx, xf, twiddles, nlon, out_dtype, kmajor=False, want_sums=False):
         ctx.save_for_backward(twiddles)
         ctx.mmax = xf.shape[1] if kmajor else xf.shape[0]
         ctx.kmajor = kmajor
+        if want_sums:            # (x, row statistics): the sums are data for the norm's kernel, not a differentiable output
+            x, sums = irfft_sums_raw(xf, twiddles, nlon, out_dtype, kmajor)
+            ctx.mark_non_differentiable(sums)
+            return x, sums
         return irfft_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0, out_dtype, kmajor)
 
     @staticmethod
-    def backward(ctx, gx):
+    def backward(ctx, gx, *_):
         (tw,) = ctx.saved_tensors
         if gx.dtype not in (torch.float32, torch.bfloat16):
             gx = gx.float()
-        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0, ctx.kmajor), None, None, None, None
+        return rfft_raw(gx.contiguous(), tw, ctx.mmax, 1.0, 2.0, 1.0, ctx.kmajor), None, None, None, None, None
 
 
 class _RFFTpm(torch.autograd.Function):
@@ -688,18 +718,22 @@ class _RFFTpm(torch.autograd.Function):
 
 class _IRFFTpm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, xf, twiddles, nlon, out_dtype, chans, cpp):
+    def forward(ctx, xf, twiddles, nlon, out_dtype, chans, cpp, want_sums=False):
         ctx.save_for_backward(twiddles)
         ctx.cfg = (xf.shape[2], chans, cpp)
+        if want_sums:
+            x, sums = irfft_sums_raw(xf, twiddles, nlon, out_dtype, True, chans, cpp)
+            ctx.mark_non_differentiable(sums)
+            return x, sums
         return irfft_pm_raw(xf, twiddles, nlon, 1.0, 1.0, 1.0, chans, cpp, out_dtype)
 
     @staticmethod
-    def backward(ctx, gx):
+    def backward(ctx, gx, *_):
         (tw,) = ctx.saved_tensors
         mmax, chans, cpp = ctx.cfg
         if gx.dtype not in (torch.float32, torch.bfloat16):
             gx = gx.float()
-        return rfft_pm_raw(gx.contiguous(), tw, mmax, 1.0, 2.0, 1.0, chans, cpp), None, None, None, None, None
+        return rfft_pm_raw(gx.contiguous(), tw, mmax, 1.0, 2.0, 1.0, chans, cpp), None, None, None, None, None, None
 
 
 class _LegendreFwd(torch.autograd.Function):
@@ -779,16 +813,17 @@ def rfft(x, twiddles, mmax, kmajor=False):
     return _RFFT.apply(x, twiddles, mmax, kmajor)
 
 
-def irfft(xf, twiddles, nlon, out_dtype=torch.float32, kmajor=False):
-    return _IRFFT.apply(xf, twiddles, nlon, out_dtype, kmajor)
+def irfft(xf, twiddles, nlon, out_dtype=torch.float32, kmajor=False, want_sums=False):
+    """``want_sums``: returns (x, fp64 ``[BC, 2]`` row sums / sums of squares of x) -- see ``mk_irfft_sums``."""
+    return _IRFFT.apply(xf, twiddles, nlon, out_dtype, kmajor, want_sums)
 
 
 def rfft_pm(x, twiddles, mmax, chans, cpp):
     return _RFFTpm.apply(x, twiddles, mmax, chans, cpp)
 
 
-def irfft_pm(xf, twiddles, nlon, out_dtype, chans, cpp):
-    return _IRFFTpm.apply(xf, twiddles, nlon, out_dtype, chans, cpp)
+def irfft_pm(xf, twiddles, nlon, out_dtype, chans, cpp, want_sums=False):
+    return _IRFFTpm.apply(xf, twiddles, nlon, out_dtype, chans, cpp, want_sums)
 
 
 def legendre_fwd(xf, table, lmax, m_off=0, kmajor=False):

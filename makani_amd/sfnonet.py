@@ -12,7 +12,7 @@ pixel-column engine, the skip convolution with the norm output as its epilogue a
 
 Spatial model parallelism (``comm.get_size("spatial") > 1``) selects the distributed transforms and
 ``DistributedInstanceNorm2d`` where the reference does (sfnonet.py:375-377, 528-533).  Channel
-("matmul") parallelism and ``layer_norm`` are outside the built hot path and raise; the non-linear (attention)
+("matmul") parallelism is outside the built hot path and raises; ``layer_norm`` runs on torch ops; the non-linear (attention)
 filter runs on the HIP transforms with a torch channel MLP in between (``spectral_convolution.SpectralAttention``).
 """
 import math
@@ -26,7 +26,7 @@ from torch.utils.checkpoint import checkpoint
 
 from . import comm
 from .distributed import DistributedInverseRealFFT2, DistributedInverseRealSHT, DistributedRealFFT2, DistributedRealSHT
-from .layer_norm import DistributedInstanceNorm2d
+from .layer_norm import DistributedInstanceNorm2d, DistributedLayerNorm
 from .layers import (Conv1x1, DropPath, EncoderDecoder, InstanceNorm2d, InverseRealFFT2, MLP, RealFFT2, _engine_field,
                      _is_exact_gelu, conv_plus_instance_norm)
 from .sht import InverseRealSHT, RealSHT
@@ -74,8 +74,11 @@ class SpectralFilterLayer(nn.Module):
             self.filter = FactorizedSpectralConv(forward_transform, inverse_transform, embed_dim, embed_dim, rank=rank,
                                                  factorization=factorization, **common)
 
-    def forward(self, x):
-        return self.filter(x)
+    def forward(self, x, want_row_sums=False):
+        if want_row_sums and isinstance(self.filter, SpectralConv) and type(self.filter).forward is SpectralConv.forward:
+            return self.filter(x, want_row_sums=True)
+        out = self.filter(x)
+        return (out[0], out[1], None) if want_row_sums else out
 
 
 class FourierNeuralOperatorBlock(nn.Module):
@@ -122,11 +125,21 @@ class FourierNeuralOperatorBlock(nn.Module):
                 and not getattr(norm, "track_running_stats", False))
 
     def forward(self, x):
-        x, residual = self.filter(x)
         inner = getattr(self, "inner_skip", None)
-        if (inner is None and isinstance(self.norm0, (InstanceNorm2d, DistributedInstanceNorm2d))
-                and _is_exact_gelu(self.act_layer0)):
-            x = self.norm0(x, fuse_gelu=True)                 # norm0 + GELU: one statistics pass, one apply pass
+        hip_norm0 = isinstance(self.norm0, (InstanceNorm2d, DistributedInstanceNorm2d)) \
+            and not getattr(self.norm0, "track_running_stats", False)
+        sums0 = None
+        if hip_norm0 and isinstance(self.filter, SpectralFilterLayer):
+            x, residual, sums0 = self.filter(x, want_row_sums=True)   # norm0's statistics come out of the inverse FFT
+        else:
+            x, residual = self.filter(x)
+        if inner is None and hip_norm0 and _is_exact_gelu(self.act_layer0):
+            x = self.norm0(x, fuse_gelu=True, row_sums=sums0)  # norm0 + GELU: (no statistics pass,) one apply pass
+        elif hip_norm0:
+            x = self.norm0(x, row_sums=sums0)
+            if inner is not None:
+                x = x + inner(residual)
+            x = self.act_layer0(x)
         else:
             x = self.norm0(x)
             if inner is not None:
@@ -217,8 +230,8 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
             return partial(InstanceNorm2d, num_features=embed_dim, eps=1e-6, affine=True, track_running_stats=False)
         if kind == "none":
             return nn.Identity
-        if kind == "layer_norm":
-            raise NotImplementedError("layer_norm normalisation is outside the built hot path (instance_norm / none)")
+        if kind == "layer_norm":       # sfnonet.py:371-373: channel-wise layer norm per grid point (torch ops; not the benchmarked norm)
+            return partial(DistributedLayerNorm, normalized_shape=(embed_dim), elementwise_affine=True, eps=1e-6)
         raise NotImplementedError(f"Error, normalization {kind} not implemented.")
 
     def _init_spectral_transforms(self, spectral_transform="sht", model_grid_type="equiangular",

@@ -78,10 +78,16 @@ class InverseRealSHT(_SHTBase):
         super().__init__(nlat, nlon, lmax, mmax, grid, norm, csphase)
         self.register_buffer("pct", ops.legendre_table(grid, nlat, self.lmax, self.mmax, False), persistent=False)
 
-    def inverse_packed(self, c, out_dtype=torch.float32):
-        """spectrum [lmax, mmax, BC] -> x [BC, nlat, nlon] (fp32, or bf16 rows straight from the FFT kernel)."""
+    def inverse_packed(self, c, out_dtype=torch.float32, want_row_sums=False):
+        """spectrum [lmax, mmax, BC] -> x [BC, nlat, nlon] (fp32, or bf16 rows straight from the FFT kernel); with
+        ``want_row_sums`` (and a length the split kernels serve) also the fp64 ``[BC, 2]`` sums / sums of squares of the rows of x
+        -- the statistics of the instance norm that reads x next -- else None in their place."""
         km = ops.SPECTRAL_GEMM == "bf16x3"
         xf = ops.legendre_inv(c, self.pct, self.nlat, 0, km)
+        if want_row_sums:
+            if ops.irfft_sums_supported(self.nlon, self.mmax) and out_dtype in (torch.float32, torch.bfloat16):
+                return ops.irfft(xf, self.twiddles, self.nlon, out_dtype, km, True)
+            return ops.irfft(xf, self.twiddles, self.nlon, out_dtype, km), None
         return ops.irfft(xf, self.twiddles, self.nlon, out_dtype, km)
 
     def forward(self, x):

@@ -114,7 +114,7 @@ class SpectralConv(nn.Module):
     def _weight_tensor(self):
         return self.weight
 
-    def _forward_fused(self, x, dtype):
+    def _forward_fused(self, x, dtype, want_row_sums=False):
         B, C = x.shape[0], x.shape[1]
         ft, it = self.forward_transform, self.inverse_transform
         xin = x if x.dtype in (torch.float32, torch.bfloat16) else x.float()
@@ -130,16 +130,25 @@ class SpectralConv(nn.Module):
             r = it.inverse_packed(c, B, odt) if self._distributed else it.inverse_packed(c, odt)
             residual = r.view(B, C, r.shape[-2], r.shape[-1]).to(dtype)
         y = ops.dhconv(c, self._weight_tensor(), B, self.l_off, self.m_off)
-        out = it.inverse_packed(y, B, odt) if self._distributed else it.inverse_packed(y, odt)
+        sums = None
+        if want_row_sums:       # the inverse FFT hands over the row statistics of its output (mk_irfft_sums)
+            out, sums = it.inverse_packed(y, B, odt, True) if self._distributed else it.inverse_packed(y, odt, True)
+        else:
+            out = it.inverse_packed(y, B, odt) if self._distributed else it.inverse_packed(y, odt)
         out = out.view(B, self.out_channels, out.shape[-2], out.shape[-1])
-        return out, residual
+        return out, residual, sums
 
-    def forward(self, x):
+    def forward(self, x, want_row_sums=False):
+        """``want_row_sums`` (this package's blocks only): a third result, the fp64 ``[B*C, 2]`` sums / sums of squares of the rows
+        of the filtered field for the instance norm behind the filter, or None where the path cannot deliver them."""
         dtype = x.dtype
         residual = x
+        sums = None
         if self._fused and x.is_cuda and x.dim() == 4:
             with torch.autocast(device_type="cuda", enabled=False):
-                x, residual = self._forward_fused(x, dtype)
+                x, residual, sums = self._forward_fused(x, dtype, want_row_sums and not hasattr(self, "bias"))
+            if sums is not None and x.dtype != dtype:
+                sums = None                         # a cast behind the kernel: the statistics are those of other values
         else:
             x = x.float()
             with torch.autocast(device_type=x.device.type, enabled=False):
@@ -154,7 +163,7 @@ class SpectralConv(nn.Module):
         if hasattr(self, "bias"):
             x = x + self.bias
         x = x.to(dtype=dtype)
-        return x, residual
+        return (x, residual, sums) if want_row_sums else (x, residual)
 
 
 class _DenseFactorizedWeight(nn.Module):

@@ -276,6 +276,18 @@ class FourierNeuralOperatorBlock(nn.Module):
         return x
 
 
+class ChannelLayerNorm(nn.Module):
+    """``DistributedLayerNorm`` of makani/mpu/layer_norm.py:117-155 (single rank): NCHW -> channels last, ``nn.LayerNorm``
+    (attribute ``norm``, so the parameter names match), back."""
+
+    def __init__(self, num_features, eps=1e-6):
+        super().__init__()
+        self.norm = nn.LayerNorm(num_features, eps=eps, elementwise_affine=True)
+
+    def forward(self, x):
+        return torch.transpose(self.norm(torch.transpose(x, 1, 3)), 1, 3).contiguous()
+
+
 class SphericalFourierNeuralOperatorNet(nn.Module):
     """sfnonet.py:270-640 (spectral_transform="sht", linear filter, serial)."""
 
@@ -312,6 +324,10 @@ class SphericalFourierNeuralOperatorNet(nn.Module):
                 return nn.InstanceNorm2d(embed_dim, eps=1e-6, affine=True, track_running_stats=False)
         elif normalization_layer == "none":
             norm = nn.Identity
+        elif normalization_layer == "layer_norm":
+            # sfnonet.py:371-373 with mpu/layer_norm.py:117-155: nn.LayerNorm over the channel axis, per grid point
+            def norm():
+                return ChannelLayerNorm(embed_dim, eps=1e-6)
         else:
             raise NotImplementedError(normalization_layer)
 

@@ -482,6 +482,40 @@ def test_fft_peer_major_layout(dev, nlat, nlon, mmax, B, C, cpp):
     assert torch.equal(yb, ops.irfft_raw(a, tw, nlon, 1.0, 1.0, 1.0, torch.bfloat16, kmajor=True))
 
 
+@pytest.mark.parametrize("nlat,nlon,mmax,B,C,cpp", [(5, 480, 33, 2, 48, 24), (3, 1440, 241, 1, 96, 48), (7, 480, 241, 1, 20, 0),
+                                                     (2, 1440, 200, 2, 9, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_irfft_row_statistics(dev, nlat, nlon, mmax, B, C, cpp, dtype):
+    """mk_irfft_sums: the inverse FFT's by-product -- per output row (b, c) the sum and the sum of squares over latitudes and
+    longitudes, ON THE VALUES AS STORED (bf16 rows: the rounded ones) -- against float64 sums of the rows it wrote; the rows
+    themselves bit-identical to the plain launch.  Peer-major and latitude-major Fourier rows, ragged channel tiles (20, 9),
+    truncated modes."""
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(16)
+    tw = ops.fft_twiddles(nlon).to(dev)
+    xf = torch.complex(torch.randn(nlat, mmax, B * C, generator=g), torch.randn(nlat, mmax, B * C, generator=g)).to(dev)
+    plain = ops.irfft_raw(xf, tw, nlon, 1.0, 1.0, 1.0, dtype, kmajor=True)
+    if cpp:
+        pm = xf.view(nlat, mmax, B, C // cpp, cpp).permute(3, 0, 1, 2, 4).reshape(C // cpp, nlat, mmax, B * cpp).contiguous()
+        x, sums = ops.irfft_sums_raw(pm, tw, nlon, dtype, True, C, cpp)
+    else:
+        x, sums = ops.irfft_sums_raw(xf, tw, nlon, dtype, True)
+    assert torch.equal(x, plain) and sums.shape == (B * C, 2) and sums.dtype == torch.float64
+    xd = x.double()
+    want = torch.stack([xd.sum(dim=(1, 2)), (xd * xd).sum(dim=(1, 2))], dim=1)
+    # fp32 partial sums per 480-real sub-row, fp64 across rows: relative to the sum of |x| resp. x^2
+    scale = torch.stack([xd.abs().sum(dim=(1, 2)), (xd * xd).sum(dim=(1, 2))], dim=1)
+    assert ((sums - want).abs() / scale).max().item() < 2e-6
+    # the autograd op: (x, sums), gradient of x only
+    xf2 = xf.clone().requires_grad_(True)
+    y, s2 = ops.irfft(xf2, tw, nlon, dtype, True, True)
+    assert torch.equal(s2, sums) and not s2.requires_grad
+    y.float().square().sum().backward()
+    xf3 = xf.clone().requires_grad_(True)
+    ops.irfft(xf3, tw, nlon, dtype, True).float().square().sum().backward()
+    assert torch.equal(xf2.grad, xf3.grad)
+
+
 def test_adam_step_matches_torch(dev):
     """mk_adam_step (one streaming pass, makani_amd/optim.py) against torch.optim.Adam over three steps, on a real
     tensor, a complex one and a permuted-contiguous one (the dhconv weight layout), with weight decay."""

@@ -152,10 +152,12 @@ def test_sfno_net_vs_oracle(dev, kw):
 
 
 @pytest.mark.parametrize("extra", [dict(pos_embed="direct"), dict(pos_embed="frequency"), dict(repeat_layers=2),
-                                   dict(checkpointing=3), dict(checkpointing=1, pos_embed="frequency", repeat_layers=2)])
+                                   dict(checkpointing=3), dict(checkpointing=1, pos_embed="frequency", repeat_layers=2),
+                                   dict(normalization_layer="layer_norm"), dict(normalization_layer="none")])
 def test_sfno_optional_branches_vs_oracle(dev, extra):
-    """pos_embed (sfnonet.py:469-501, 606-618), repeat_layers and the activation-checkpointing levels (574-585):
-    forward, input gradient and every parameter gradient against the oracle."""
+    """pos_embed (sfnonet.py:469-501, 606-618), repeat_layers, the activation-checkpointing levels (574-585) and the other
+    normalisation choices (371-382: channel-wise layer norm, none): forward, input gradient and every parameter gradient
+    against the oracle."""
     from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
     from oracle import spectral as osp
     torch.manual_seed(21)
