@@ -280,7 +280,7 @@ template <> struct OutVec<__hip_bfloat16> {
 // PERSIST = 1: workgroups walk the tiles with the next tile's mode gather in flight under the current tile's passes (32 prefetch
 // registers: 167 VGPRs, two workgroups per CU).  PERSIST = 0: one tile per workgroup, nothing prefetched, the pass twiddles loaded
 // after the merge step -- registers for five waves per SIMD, i.e. three workgroups per CU covering each other like the forward kernel.
-template <int S, typename TOut, bool WIDE, int PERSIST>
+template <int S, typename TOut, bool WIDE, int PERSIST, bool SUMS = false>
 __global__ __launch_bounds__(STHREADS, PERSIST ? 3 : 5) void irfft_split_kernel(const float2* __restrict__ xf, TOut* __restrict__ x,
                                                                const float2* __restrict__ tw, int BC, int K, int M,
                                                                float scale0, float scale_m, float scale_h, XfLayout xl,
@@ -410,10 +410,10 @@ __global__ __launch_bounds__(STHREADS, PERSIST ? 3 : 5) void irfft_split_kernel(
     __syncthreads();
     const int next = PERSIST ? next_valid(sched + (int)gridDim.x) : total16;
     if (next < total16) gather(pair_tile(next), opaque(tid));
-    if (rowsums != nullptr) split_passes<true, TOut>(lds, tl, S, tw15, red);
+    if constexpr (SUMS) split_passes<true, TOut>(lds, tl, S, tw15, red);
     else split_passes(lds, tl, S, tw15);
     __syncthreads();
-    if (rowsums != nullptr && tl < 2 * G) {      // one fp64 atomic per (channel, statistic) and tile: the row's share of the field sums
+    if (SUMS && tl < 2 * G) {      // one fp64 atomic per (channel, statistic) and tile: the row's share of the field sums
         const int gch = tl >> 1, t = tl & 1;
         if (bc0 + gch < BC) {
             float v = 0.f;
@@ -502,14 +502,21 @@ int launch_irfft_split(const float* xf, void* x, int x_dtype, const float* tw, i
     // 32-bit mode offsets inside a tile's buffer descriptor: (240 modes + one row of channels) * 8 bytes must stay below 2^31
     const long long bcx = g_xl.Cp ? (long long)g_xl.Bn * g_xl.Cp : (long long)bc;
     const bool wide = ((long long)SH * g_xl.sm + 1) * bcx * 8 >= (1LL << 31);
-#define MK_IRFFT_LAUNCH(T, W, PS)                                                                                      \
-    hipLaunchKernelGGL((irfft_split_kernel<S, T, W, PS>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,        \
+#define MK_IRFFT_LAUNCH(T, W, PS, SM)                                                                                  \
+    hipLaunchKernelGGL((irfft_split_kernel<S, T, W, PS, SM>), grid, dim3(STHREADS), lds, st, (const float2*)xf, (T*)x,    \
                        (const float2*)tw, bc, nlat, mmax, s0, sm, sh, g_xl, g_rowsums)
-    if (x_dtype == 0) {
-        if (wide) MK_IRFFT_LAUNCH(float, true, 1); else MK_IRFFT_LAUNCH(float, false, 0);
-    } else {
-        if (wide) MK_IRFFT_LAUNCH(__hip_bfloat16, true, 1); else MK_IRFFT_LAUNCH(__hip_bfloat16, false, 0);
+#define MK_IRFFT_PICK(T)                                                                                               \
+    if (g_rowsums) {                                                                                                   \
+        if (wide) MK_IRFFT_LAUNCH(T, true, 1, true); else MK_IRFFT_LAUNCH(T, false, 0, true);                          \
+    } else {                                                                                                           \
+        if (wide) MK_IRFFT_LAUNCH(T, true, 1, false); else MK_IRFFT_LAUNCH(T, false, 0, false);                        \
     }
+    if (x_dtype == 0) {
+        MK_IRFFT_PICK(float)
+    } else {
+        MK_IRFFT_PICK(__hip_bfloat16)
+    }
+#undef MK_IRFFT_PICK
 #undef MK_IRFFT_LAUNCH
     return 0;
 }
