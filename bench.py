@@ -124,11 +124,21 @@ class KernelTimer:
             m, k, bc = (xf.shape[1], xf.shape[0], xf.shape[2]) if kmajor else xf.shape
             return float(k * bc * (out.element_size() * nlon + 8 * m)), "byte"
 
+        def irfft_sums_work(out, xf, tw, nlon, out_dtype, kmajor=False, chans=0, cpp=0, **_):
+            # the inverse FFT that also delivers the row statistics of its output (norm0's first pass): same bytes
+            x = out[0]
+            if cpp:
+                k, m = xf.shape[1], xf.shape[2]
+            else:
+                m, k = (xf.shape[1], xf.shape[0]) if kmajor else (xf.shape[0], xf.shape[1])
+            return float(k * x.shape[0] * (x.element_size() * nlon + 8 * m)), "byte"
+
         def layout_work(out, t, *a):
             return float(2 * 8 * t.numel()), "byte"
 
         ops.rfft_raw = wrap("rfft", ops.rfft_raw, rfft_work)
         ops.irfft_raw = wrap("irfft", ops.irfft_raw, irfft_work)
+        ops.irfft_sums_raw = wrap("irfft", ops.irfft_sums_raw, irfft_sums_work)
         ops.legendre_fwd_raw = wrap("legendre_fwd", ops.legendre_fwd_raw, leg_fwd_work)
         ops.legendre_inv_raw = wrap("legendre_inv", ops.legendre_inv_raw, leg_inv_work)
         ops.dhconv_fwd_raw = wrap("dhconv_fwd", ops.dhconv_fwd_raw, dh_work)

@@ -219,6 +219,11 @@ int mk_instnorm_fwd_ex(const void* x, const float* weight, const float* bias, vo
 int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const float* weight, const float* bias,
                        void* gx, double* workspace, int dtype, int rows, int C, long long P, long long count,
                        int fuse_gelu, int phase, void* stream);
+/* mk_instnorm_bwd for one sample (rows = C) that also writes the gradients of the affine parameters: gwb fp32 [2][C], row 0 =
+ * weight gradient (sum g' xhat), row 1 = bias gradient (sum g'), the backward of `nn.InstanceNorm2d(affine=True)`'s parameters
+ * (sfnonet.py:239-253) without a copy / cast launch behind the kernel. */
+int mk_instnorm_bwd_wb(const void* x, const void* gy, const float* stats, const float* weight, const float* bias, void* gx,
+                       double* workspace, float* gwb, int dtype, int C, long long P, int fuse_gelu, void* stream);
 
 /* ---- 1x1 convolution weight gradient (bf16 MFMA) ------------------------------------------ */
 /* Latitude-weighted squared error of the training harness (latitude weights as in

@@ -63,6 +63,7 @@ SIGNATURES = {
                                     ctypes.c_longlong, _c_float, _c_int, _c_int, _vp]),
     "mk_instnorm_bwd_ex": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong,
                                     ctypes.c_longlong, _c_int, _c_int, _vp]),
+    "mk_instnorm_bwd_wb": (_c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_int, _c_int, ctypes.c_longlong, _c_int, _vp]),
     "mk_wmse_fwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_wmse_bwd": (_c_int, [_vp, _c_int, _vp, _vp, _vp, _vp, ctypes.c_longlong, _c_int, _c_int, _c_float, _vp]),
     "mk_conv1x1_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),

@@ -353,6 +353,9 @@ __device__ __forceinline__ void x3_mfma_step(const char* As, const char* Bs, con
                 for (int t = 0; t < 6; ++t)
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
+#if defined(MK_X3_SKIP25)      // experiment (wrong results): a quarter of the MFMAs gone -- what a 3-multiplication complex product could gain at best
+                        if (s == 1 && b == 1) continue;
+#endif
 #if defined(MK_X3_NOMFMA)      // experiment: the LDS reads stay, the matrix instruction becomes one VALU op
                         acc[a][b][t] += __builtin_bit_cast(float4, af[PA[t]]).x * __builtin_bit_cast(float4, bf[b][PB[t]]).y;
 #elif defined(MK_X3_AGPR)      // experiment: accumulators in the AccVGPR half of the register file

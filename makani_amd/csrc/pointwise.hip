@@ -283,11 +283,17 @@ __global__ __launch_bounds__(kT) void instnorm_bwd_apply_kernel(const T* __restr
                                                                 const float* __restrict__ stats,
                                                                 const float* __restrict__ w, const float* __restrict__ b,
                                                                 const double* __restrict__ sums, T* __restrict__ gx, int C,
-                                                                long long P, double count) {
+                                                                long long P, double count, float* __restrict__ gwb) {
     const int row = blockIdx.y, c = row % C;
     const float mean = stats[2 * row], rstd = stats[2 * row + 1];
     const float wc = w ? w[c] : 1.f, bc = b ? b[c] : 0.f;
     const float m1 = (float)(sums[2 * row] / count), m2 = (float)(sums[2 * row + 1] / count);
+    // one sample per parameter row (rows == C): the row sums ARE the affine parameters' gradients -- gwb[0][c] = weight
+    // gradient (sum g' xhat), gwb[1][c] = bias gradient (sum g'); saves the caller a copy / cast launch per norm
+    if (gwb != nullptr && blockIdx.x == 0 && threadIdx.x == 0) {
+        gwb[c] = (float)sums[2 * row + 1];
+        gwb[C + c] = (float)sums[2 * row];
+    }
     const float k = wc * rstd;
     const long long ro = (long long)row * P;
     for_chunk<T>(P, [&](long long off, int n) {
@@ -437,10 +443,11 @@ extern "C" int mk_instnorm_coeffs(const double* sums, const float* weight, const
 
 // phases as in mk_instnorm_fwd_ex; the phase-1 sums (sum g', sum g' xhat per row) are also the LOCAL bias / weight
 // gradient contributions
-extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const float* weight,
-                                  const float* bias, void* gx, double* workspace, int dtype, int rows, int C, long long P,
-                                  long long count, int fuse_gelu, int phase, void* stream) {
+static int instnorm_bwd_launch(const void* x, const void* gy, const float* stats, const float* weight,
+                               const float* bias, void* gx, double* workspace, int dtype, int rows, int C, long long P,
+                               long long count, int fuse_gelu, int phase, float* gwb, void* stream) {
     MK_REQUIRE(x && gy && stats && workspace, "null pointer");
+    MK_REQUIRE(gwb == nullptr || (rows == C && phase == 0), "parameter gradients from the kernel: one sample, unsharded rows only");
     MK_REQUIRE(phase == 1 || gx, "null pointer");
     MK_REQUIRE(phase >= 0 && phase <= 2 && count > 0, "bad phase / count");
     PW_CHECK();
@@ -454,7 +461,7 @@ extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* st
                            bias, workspace, C, P);                                                                 \
     if (phase != 1)                                                                                                \
         hipLaunchKernelGGL((instnorm_bwd_apply_kernel<T, G>), g, dim3(kT), 0, st, (const T*)x, (const T*)gy, stats, weight, \
-                           bias, workspace, (T*)gx, C, P, cnt);
+                           bias, workspace, (T*)gx, C, P, cnt, gwb);
     if (dtype == 0) {
         if (fuse_gelu) { LAUNCH(float, true) } else { LAUNCH(float, false) }
     } else {
@@ -463,6 +470,20 @@ extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* st
 #undef LAUNCH
     MK_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mk_instnorm_bwd_ex(const void* x, const void* gy, const float* stats, const float* weight,
+                                  const float* bias, void* gx, double* workspace, int dtype, int rows, int C, long long P,
+                                  long long count, int fuse_gelu, int phase, void* stream) {
+    return instnorm_bwd_launch(x, gy, stats, weight, bias, gx, workspace, dtype, rows, C, P, count, fuse_gelu, phase, nullptr, stream);
+}
+
+// mk_instnorm_bwd that also writes the affine parameters' gradients (fp32 [2][C]: weight row, bias row) -- batch 1 only
+extern "C" int mk_instnorm_bwd_wb(const void* x, const void* gy, const float* stats, const float* weight,
+                                  const float* bias, void* gx, double* workspace, float* gwb, int dtype, int C, long long P,
+                                  int fuse_gelu, void* stream) {
+    MK_REQUIRE(gwb != nullptr, "null pointer");
+    return instnorm_bwd_launch(x, gy, stats, weight, bias, gx, workspace, dtype, C, C, P, P, fuse_gelu, 0, gwb, stream);
 }
 
 extern "C" int mk_instnorm_bwd(const void* x, const void* gy, const float* stats, const float* weight,

@@ -957,6 +957,13 @@ def instance_norm_backward(x, gy, stats, wf, bf, fuse_gelu=False, group=None, co
                                           wf.data_ptr() if wf is not None else 0, bf.data_ptr() if bf is not None else 0,
                                           gx.data_ptr(), ws.data_ptr(), _pw_dtype(x), B * C, C, H * W, cnt, int(fuse_gelu),
                                           phase, _stream()), "mk_instnorm_bwd_ex")
+    if group is None and B == 1 and grad_dtype == torch.float32 and wf is not None and bf is not None:
+        # one sample: the kernel writes the affine parameters' gradients itself (no copy / cast launch behind it)
+        out = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        _lib.check(lib.mk_instnorm_bwd_wb(x.data_ptr(), gy.data_ptr(), stats.data_ptr(), wf.data_ptr(), bf.data_ptr(),
+                                          gx.data_ptr(), ws.data_ptr(), out.data_ptr(), _pw_dtype(x), C, H * W, int(fuse_gelu),
+                                          _stream()), "mk_instnorm_bwd_wb")
+        return gx, out[0], out[1]
     if group is None:
         run(0)
         local = ws
