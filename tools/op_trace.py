@@ -52,3 +52,28 @@ small.sort(reverse=True)
 for c, t, k, sh in small[:60]:
     print(f"x{c:4d}  {t / 1e3:7.3f} ms  {k[:60]:60s} {sh}")
 print(f"# kernels launched in the step: {sum(e.count for e in prof.key_averages() if e.device_time_total > 0 and ('void ' in e.key or 'anonymous namespace' in e.key or 'Memcpy' in e.key or 'Memset' in e.key))}")
+
+if os.environ.get("MK_TRACE_FILLS", "0") == "1":
+    # who issues the zero fills: python call sites of aten::fill_ / zero_ / zeros that launch a kernel
+    import collections
+    import traceback
+    sites = collections.Counter()
+    orig = {}
+
+    def spy(name, fn):
+        def inner(*a, **k):
+            fr = [f for f in traceback.extract_stack()[:-1] if "/makani_amd/" in f.filename or f.filename.endswith("bench.py")]
+            sites[(name,) + tuple(f"{os.path.basename(f.filename)}:{f.lineno}" for f in fr[-2:])] += 1
+            return fn(*a, **k)
+        return inner
+    for name in ("zeros", "zeros_like", "full", "ones"):
+        orig[name] = getattr(torch, name)
+        setattr(torch, name, spy(name, orig[name]))
+    for name in ("zero_", "fill_", "new_zeros"):
+        orig["T." + name] = getattr(torch.Tensor, name)
+        setattr(torch.Tensor, name, spy("T." + name, orig["T." + name]))
+    step()
+    torch.cuda.synchronize()
+    print("\n# python call sites of zero fills in one step")
+    for k, c in sites.most_common(40):
+        print(f"x{c:4d}  {' <- '.join(k)}")
