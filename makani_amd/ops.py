@@ -427,7 +427,10 @@ class EngineArena:
     own, a checkpoint recomputation -- every call packs / allocates for itself as before."""
 
     def __init__(self, weights):
-        self.weights = [w for w in weights if w.is_cuda and w.dim() == 2 and w.stride(1) == 1
+        # detached: only addresses and shapes are kept.  (A `weight.view(out, in)` of a parameter carries a grad_fn that holds
+        # the parameter's AccumulateGrad node; keeping it across steps pins that node to the stream of the first step and a
+        # later capture on another stream dies in capture_end -- the round-1 crash, DESIGN.md 6.1.)
+        self.weights = [w.detach() for w in weights if w.is_cuda and w.dim() == 2 and w.stride(1) == 1
                         and w.dtype in (torch.float32, torch.bfloat16)]
         lib = _lib.load()
         rows, self.slots, off, goff = [], {}, 0, 0

@@ -499,3 +499,37 @@ def test_fused_adam_state_dict_round_trip_and_foreign_layout(dev):
     opt2.load_state_dict(sd)
     for a, b in zip(opt2.state_dict()["big"], sd["big"]):
         assert torch.equal(a["m"], b["m"]) and torch.equal(a["v"], b["v"]) and a["step"] == b["step"]
+
+
+def test_capture_after_eager_steps_on_the_default_stream(dev):
+    """`bench.py --graph`'s sequence: eager warm-up steps on the DEFAULT stream, nothing of their autograd graphs kept, then
+    `torch.cuda.graph` (capture on a side stream) of forward + loss + backward, replay.  Round 3 broke it once: the per-step arena
+    kept `weight.view(out, in)` tensors, whose grad_fn pins each parameter's AccumulateGrad node to the stream of the first
+    step -- `capture_end` then dies (the round-1 crash).  The arena keeps detached views now."""
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    torch.manual_seed(11)
+    kw = dict(inp_shape=(32, 64), out_shape=(32, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=16, num_layers=2)
+    net = SphericalFourierNeuralOperatorNet(**kw).to(dev)
+    x, tar = torch.randn(2, 4, 32, 64, device=dev), torch.randn(2, 3, 32, 64, device=dev)
+
+    def fwd_bwd():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = net(x)
+        loss = ((pred.float() - tar) ** 2).mean()
+        loss.backward()
+        return loss
+
+    for _ in range(2):                       # eager, default stream; the loss is dropped at once
+        net.zero_grad(set_to_none=True)
+        float(fwd_bwd())
+    ref = {n: p.grad.clone() for n, p in net.named_parameters()}
+    net.zero_grad(set_to_none=True)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        static_loss = fwd_bwd()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.isfinite(static_loss).all()
+    for n, p in net.named_parameters():
+        assert p.grad is not None and rel(p.grad, ref[n], floor=1e-6) < 1e-3, n
