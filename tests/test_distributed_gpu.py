@@ -328,10 +328,12 @@ def _body_sht_prod(dev):
 
 
 def _body_net_prod(dev):
-    """configs[3]: sfno_linear_73chq_sc3_layers8_edim384 forward with h_parallel_size = 4 on the real kernels (fp32), every rank's
-    latitude shard of the output against the serial fp32 oracle (one oracle forward on rank 0, broadcast)."""
+    """configs[3]: sfno_linear_73chq_sc3_layers8_edim384 forward AND backward with h_parallel_size = 4 on the real kernels (fp32):
+    every rank's latitude shard of the output and of the input gradient, and a sample of parameter gradients (shared weights after
+    the SUM over `h` of `mappings.reduce_shared_gradients`, the l-sharded spectral weight shard by shard), against ONE oracle step
+    on rank 0 (broadcast).  The loss is `sum(y * g)` with a fixed random field g, so the local losses add up to the serial one."""
     import bench
-    from makani_amd import comm
+    from makani_amd import comm, mappings
     from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
     from makani_amd.distributed import compute_split_shapes
     from oracle import spectral as osp
@@ -348,18 +350,42 @@ def _body_net_prod(dev):
     net = net.to(dev)
     assert net.inp_shape_loc[0] == [181, 181, 181, 178][hr]
     xg = torch.randn(1, 73, 721, 1440)
+    gg = torch.randn(1, 73, 721, 1440)
+    shared = ["encoder.fwd.0.weight", "blocks.3.mlp.fwd.0.weight", "blocks.7.norm0.weight", "decoder.fwd.2.weight",
+              "residual_transform.weight"]
+    sharded = "blocks.0.filter.filter.weight"
+    shapes = {n: tuple(p.shape) for n, p in ref.named_parameters()}
     if comm.get_world_rank() == 0:
         torch.set_num_threads(16)
-        with torch.no_grad():
-            yo = ref(xg)
+        xo = xg.clone().requires_grad_(True)
+        yo = ref(xo)
+        (yo * gg).sum().backward()
+        yo, gxo = yo.detach(), xo.grad
+        po = {n: p.grad for n, p in ref.named_parameters() if n in shared or n == sharded}
     else:
-        yo = None
+        yo = gxo = None
+        po = {}
     del ref
     yo = _bcast_from0(yo, (1, 73, 721, 1440), torch.float32)
-    with torch.no_grad():
-        yl = net(_shard(xg, 2, "h").to(dev))
+    gxo = _bcast_from0(gxo, (1, 73, 721, 1440), torch.float32)
+    want = {n: _bcast_from0(po.get(n), shapes[n], torch.complex64 if n == sharded else torch.float32) for n in shared + [sharded]}
+    xl = _shard(xg, 2, "h").to(dev).requires_grad_(True)
+    yl = net(xl)
+    (yl * _shard(gg, 2, "h").to(dev)).sum().backward()
+    mappings.reduce_shared_gradients(net)
     err = _rel(yl, _shard(yo, 2, "h"))
     assert err < 2e-5, f"rank {hr}: output error {err:.3e}"
+    err = _rel(xl.grad, _shard(gxo, 2, "h"))
+    assert err < 5e-5, f"rank {hr}: input gradient error {err:.3e}"
+    pn = dict(net.named_parameters())
+    scale = float(np.median([torch.linalg.norm(want[n].to(torch.complex128) if want[n].is_complex() else want[n].double()).item()
+                             for n in shared]))
+    for n in shared:
+        err = _rel(pn[n].grad, want[n], floor=1e-1 * scale)
+        assert err < 5e-5, f"rank {hr}: gradient of {n}: {err:.3e}"
+    w = torch.split(want[sharded], compute_split_shapes(want[sharded].shape[-1], hs), dim=-1)[hr]
+    err = _rel(pn[sharded].grad, w)
+    assert err < 5e-5, f"rank {hr}: gradient of the l-sharded {sharded}: {err:.3e}"
 
 
 def _take_turns_on_the_card(lock):
