@@ -387,6 +387,23 @@ def _body_net_prod(dev):
     err = _rel(pn[sharded].grad, w)
     assert err < 5e-5, f"rank {hr}: gradient of the l-sharded {sharded}: {err:.3e}"
 
+    # the same step in the benchmark's mode -- bf16 autocast: pixel-column engine, per-step arena, the inverse FFT's row statistics
+    # through the sharded instance norm's all-reduce -- against the same fp32 oracle at bf16 tolerances (those of the
+    # single-GPU test, tests/test_parity_gpu.py: output 3e-2, input gradient 6e-2, parameter gradients 8e-2)
+    net.zero_grad(set_to_none=True)
+    xb = _shard(xg, 2, "h").to(dev).requires_grad_(True)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb = net(xb)
+    (yb.float() * _shard(gg, 2, "h").to(dev)).sum().backward()
+    mappings.reduce_shared_gradients(net)
+    e_y, e_x = _rel(yb.float(), _shard(yo, 2, "h")), _rel(xb.grad, _shard(gxo, 2, "h"))
+    assert e_y < 3e-2 and e_x < 6e-2, f"rank {hr} (bf16): output {e_y:.3e}, input gradient {e_x:.3e}"
+    for n in shared:
+        err = _rel(pn[n].grad, want[n], floor=1e-1 * scale)
+        assert err < 8e-2, f"rank {hr} (bf16): gradient of {n}: {err:.3e}"
+    err = _rel(pn[sharded].grad, w)
+    assert err < 8e-2, f"rank {hr} (bf16): gradient of the l-sharded {sharded}: {err:.3e}"
+
 
 def _take_turns_on_the_card(lock):
     """The ranks of these tests share ONE card, which production never does (one process per GPU).  Kernels of different
