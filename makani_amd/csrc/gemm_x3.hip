@@ -842,8 +842,16 @@ struct ConvX3Params {
 template <int MODE>
 __global__ __launch_bounds__(XT, 3) void conv_x3_kernel(ConvX3Params p) {
     extern __shared__ __attribute__((aligned(16))) char lds_x3[];
-    const TileId t = decode_block(p.nwork, p.tiles_m, p.tiles_n);
+    // MODE 2: work item = (batch item, pixel slab), all tiles of gW of one item on one XCD.  MODE 0 / 1: work item = (batch item,
+    // 128-pixel tile), its M / 128 row tiles back to back on one XCD -- they share the x tile, the second to sixth find it in
+    // that XCD's L2 (with the batch index as the only work index a batch of one ran on ONE of the eight XCDs: 8x slower)
+    TileId t = decode_block(p.nwork, p.tiles_m, MODE == 2 ? p.tiles_n : 1);
     if (!t.valid) return;
+    if constexpr (MODE != 2) {
+        const int w = t.batch;
+        t.batch = w / p.tiles_n;
+        t.tn = w - t.batch * p.tiles_n;
+    }
     const int m0 = t.tm * XM, n0 = t.tn * XN;
     if constexpr (MODE == 2) {
         const int b = t.batch / p.nslab, slab = t.batch - b * p.nslab;
@@ -909,9 +917,10 @@ extern "C" int mk_conv1x1_x3(const float* a, long long lda, const float* b, long
         MK_REQUIRE(lda % 4 == 0 && lda >= (K + 3) / 4 * 4, "A: the row stride must be a multiple of 4 and cover K rounded up to 4 (zero padded)");
         MK_REQUIRE(N % 2 == 0 && ldb % 2 == 0 && ldc % 2 == 0 && sb % 2 == 0 && sc % 2 == 0, "B / C: even row lengths and strides");
         MK_REQUIRE(33LL * ldb * 4 < (1LL << 31), "B row stride too large for the 32-bit offsets of one k-step");
-        p.nwork = batch;
+        MK_REQUIRE((long long)batch * p.tiles_n < 2147483647LL, "too many pixel tiles");
+        p.nwork = batch * p.tiles_n;
     }
-    const long long nblk = grid_blocks(p.nwork, p.tiles_m, p.tiles_n);
+    const long long nblk = grid_blocks(p.nwork, p.tiles_m, mode == 2 ? p.tiles_n : 1);
     MK_REQUIRE(nblk < 2147483647LL, "grid too large");
     const dim3 grid((unsigned)nblk), blk(XT);
     hipStream_t st = (hipStream_t)stream;
