@@ -245,9 +245,13 @@ class _PceMLP(torch.autograd.Function):
     wrappers that expect every parameter to get a gradient (DistributedDataParallel, ``mpu/mappings.py:86-96``) work."""
 
     @staticmethod
-    def forward(ctx, x3, w1, b1, w2, b2, apply_b2, want_row_sums):
+    def forward(ctx, x3, w1, b1, w2, b2, apply_b2, want_row_sums, keep_pre=True):
+        # keep_pre: the caller's `torch.is_grad_enabled()` (inside forward grad mode is always off, and needs_input_grad ignores it)
         from . import ops
-        h, pre = ops.pce_gemm(x3, ops.pce_pack(w1), w1.shape[0], bias=b1, want_pre=True, gelu=True)
+        if keep_pre:
+            h, pre = ops.pce_gemm(x3, ops.pce_pack(w1), w1.shape[0], bias=b1, want_pre=True, gelu=True)
+        else:       # inference: nobody will ask for GELU'(pre) -- the first launch writes the hidden field once, not twice
+            h, pre = ops.pce_gemm(x3, ops.pce_pack(w1), w1.shape[0], bias=b1, gelu=True), x3.new_empty(0)
         want_row_sums = bool(want_row_sums) and w2.shape[0] <= 768
         y = ops.pce_gemm(h, ops.pce_pack(w2), w2.shape[0], bias=b2 if (apply_b2 and b2 is not None) else None,
                          want_row_sums=want_row_sums)
@@ -286,7 +290,7 @@ class _PceMLP(torch.autograd.Function):
             gw2 = ops.conv1x1_wgrad_raw(gy, h, out=g2buf).to(w2.dtype)
         if b2_info is not None and ctx.needs_input_grad[4]:
             gb2 = _row_sums(gy).to(b2_info[0]) if apply_b2 else torch.zeros(b2_info[1], dtype=b2_info[0], device=gy.device)
-        return gx, gw1, gb1, gw2, gb2, None, None
+        return gx, gw1, gb1, gw2, gb2, None, None, None
 
 
 class _PceMLPFused(torch.autograd.Function):
@@ -436,9 +440,13 @@ def run_pointwise_chain(mods, x, skip_last_bias=False, want_row_sums=False):
         x3 = _engine_field(x)
         if (x3 is not None and ops.pce_supported_train(fc1.out_channels, fc1.in_channels)
                 and ops.pce_supported_train(fc2.out_channels, fc2.in_channels)):
-            node = _PceMLPFused if _mlp_fused_ok(fc1, fc2) else _PceMLP
+            fused = _mlp_fused_ok(fc1, fc2)
             with torch.autocast("cuda", enabled=False):
-                y, sums = node.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias, want_row_sums)
+                if fused:
+                    y, sums = _PceMLPFused.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias, want_row_sums)
+                else:       # inference (grad mode off): the pre-activation is not kept -- one 768-row store less per MLP
+                    y, sums = _PceMLP.apply(x3, fc1.weight2d(), fc1.bias, fc2.weight2d(), fc2.bias, not skip_last_bias, want_row_sums,
+                                            torch.is_grad_enabled())
             y = y.view(x.shape[0], fc2.out_channels, x.shape[2], x.shape[3])
             return (y, sums if sums.numel() else None) if want_row_sums else y
     last_conv = max((j for j, m in enumerate(mods) if isinstance(m, Conv1x1)), default=-1)
