@@ -133,12 +133,22 @@ class KernelTimer:
                 m, k = (xf.shape[1], xf.shape[0]) if kmajor else (xf.shape[0], xf.shape[1])
             return float(k * x.shape[0] * (x.element_size() * nlon + 8 * m)), "byte"
 
+        def rfft_pm_work(out, x, tw, mmax, *s, **kw):        # peer-major Fourier rows (latitude-sharded transform): same bytes
+            bc, k, n = x.shape
+            return float(k * bc * (x.element_size() * n + 8 * mmax)), "byte"
+
+        def irfft_pm_work(out, xf, tw, nlon, *s, **kw):
+            p, k, m, bcp = xf.shape
+            return float(k * out.shape[0] * (out.element_size() * nlon + 8 * m)), "byte"
+
         def layout_work(out, t, *a):
             return float(2 * 8 * t.numel()), "byte"
 
         ops.rfft_raw = wrap("rfft", ops.rfft_raw, rfft_work)
         ops.irfft_raw = wrap("irfft", ops.irfft_raw, irfft_work)
         ops.irfft_sums_raw = wrap("irfft", ops.irfft_sums_raw, irfft_sums_work)
+        ops.rfft_pm_raw = wrap("rfft", ops.rfft_pm_raw, rfft_pm_work)
+        ops.irfft_pm_raw = wrap("irfft", ops.irfft_pm_raw, irfft_pm_work)
         ops.legendre_fwd_raw = wrap("legendre_fwd", ops.legendre_fwd_raw, leg_fwd_work)
         ops.legendre_inv_raw = wrap("legendre_inv", ops.legendre_inv_raw, leg_inv_work)
         ops.dhconv_fwd_raw = wrap("dhconv_fwd", ops.dhconv_fwd_raw, dh_work)
