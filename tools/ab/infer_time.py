@@ -23,3 +23,23 @@ with torch.no_grad():
     t0, y0 = run()
 t1, y1 = run()
 print(f"forward only: no_grad {t0:.3f} ms, with autograd bookkeeping {t1:.3f} ms; outputs identical: {torch.equal(y0, y1.detach())}")
+
+
+def run32(n=4):
+    for _ in range(2):
+        y = net(x)
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(n):
+        y = net(x)
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / n
+
+
+with torch.no_grad():
+    t32 = run32()
+os.environ["MK_CONV_FP32"] = "torch"
+with torch.no_grad():
+    t32v = run32()
+print(f"forward only, fp32 (no autocast): {t32:.3f} ms on the bf16x3 engine; {t32v:.3f} ms with the vendor GEMM for the 1x1 convolutions (MK_CONV_FP32=torch)")
