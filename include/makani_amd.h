@@ -242,6 +242,10 @@ int mk_wmse_bwd(const void* pred, int dtype, const float* tar, const float* wrow
  * sa / sb / sc = batch strides in elements.  Replaces F.conv2d / its gradients behind nn.Conv2d(.., 1) in fp32 mode (layers.py:95-206). */
 int mk_conv1x1_x3(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K, long long N,
                   int batch, long long sa, long long sb, long long sc, int mode, void* stream);
+/* c[b] = act(a b[b] + bias): mode 0 with the bias add (bias fp32 [M] or NULL) and, with act = 1, the exact (erf) GELU in the epilogue:
+ * `nn.Conv2d(cin, cout, 1, bias=True)` followed by `nn.GELU()` (layers.py:95-99, 158-206) in one pass over the output. */
+int mk_conv1x1_x3_bias_act(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K,
+                           long long N, int batch, long long sb, long long sc, const float* bias, int act, void* stream);
 
 /* gw[o][i] += sum over (b, p) of gy[b][o][p] * x[b][i][p]; gy, x bf16 [B][C][P] (P multiple of 8), gw fp32
  * [cout][cin] accumulated with atomics (caller zeroes it).  The weight gradient of nn.Conv2d(cin, cout, 1)

@@ -69,6 +69,8 @@ SIGNATURES = {
     "mk_conv1x1_wgrad": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _vp]),
     "mk_conv1x1_x3": (_c_int, [_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int, _c_int, ctypes.c_longlong,
                                _c_int, ctypes.c_longlong, ctypes.c_longlong, ctypes.c_longlong, _c_int, _vp]),
+    "mk_conv1x1_x3_bias_act": (_c_int, [_vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _vp, ctypes.c_longlong, _c_int, _c_int,
+                                        ctypes.c_longlong, _c_int, ctypes.c_longlong, ctypes.c_longlong, _vp, _c_int, _vp]),
     "mk_conv1x1_wgrad_act": (_c_int, [_vp, _vp, _vp, _c_int, _c_int, _c_int, ctypes.c_longlong, _c_int, _vp]),
     "mk_pce_mlp_image_bytes": (ctypes.c_longlong, [_c_int, _c_int, _c_int]),
     "mk_pce_mlp_pack": (_c_int, [_vp, _c_int, _c_int, _vp, _c_int, _c_int, _c_int, _c_int, _c_int, _c_int, _vp, _vp]),

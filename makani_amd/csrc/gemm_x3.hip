@@ -377,10 +377,11 @@ __device__ __forceinline__ void x3_mfma_step(const char* As, const char* Bs, con
 // The B operand streams from HBM: it is prefetched DB k-steps ahead through a ring of register sets (the
 // loop is unrolled DB times so ring slots are compile-time); the A operand (L2-resident panels) one ahead.
 // EPI: 0 = store (nontemporal), 1 = C += tile (read-modify-write by the one workgroup that owns the tile), 2 = atomic adds
-// (several workgroups contract disjoint k ranges into one tile)
+// (several workgroups contract disjoint k ranges into one tile), 3 = store act(tile + bias[row]) with `rowbias` pointing at the
+// tile's first row (null: no bias) and `act` != 0 the exact (erf) GELU: conv + bias + activation of layers.py:158-206 in one launch
 template <int DB, class AS, class BS, int EPI = 0>
 __device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int kt1, int rvalid, int cvalid, float* cbase,
-                                        long long ldc, char* lds, int exp = 0) {
+                                        long long ldc, char* lds, int exp = 0, const float* rowbias = nullptr, int act = 0) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: liveness tests stay scalar
     const int wr = wave >> 1, wc = wave & 1;
@@ -463,6 +464,15 @@ __device__ __forceinline__ void x3_tile(const AS& as, const BS& bs, int kt0, int
                     } else if constexpr (EPI == 2) {
                         atomicAdd(cbase + (long long)row * ldc + col, acc[a][0][r]);
                         if (col + 1 < cvalid) atomicAdd(cbase + (long long)row * ldc + col + 1, acc[a][1][r]);
+                        continue;
+                    } else if constexpr (EPI == 3) {
+                        const float bv = rowbias ? rowbias[row] : 0.f;
+                        float v0 = acc[a][0][r] + bv, v1 = acc[a][1][r] + bv;
+                        if (act) {
+                            v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752440f));
+                            v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
+                        }
+                        *reinterpret_cast<float2*>(cbase + (long long)row * ldc + col) = make_float2(v0, v1);
                         continue;
                     }
 #ifndef MK_X3_PLAIN_STORE
@@ -838,6 +848,8 @@ struct ConvX3Params {
     float* c;
     long long lda, ldb, ldc, sa, sb, sc;
     int M, K, N, nwork, tiles_m, tiles_n, nslab, kslab;
+    const float* bias;      // mode 3: per-row bias or null
+    int act;                // mode 3: 1 = exact GELU
 };
 template <int MODE>
 __global__ __launch_bounds__(XT, 3) void conv_x3_kernel(ConvX3Params p) {
@@ -880,22 +892,25 @@ __global__ __launch_bounds__(XT, 3) void conv_x3_kernel(ConvX3Params p) {
         bs.k_hi = p.K;
         bs.cvalid = p.N - n0;
         x3_tile<X3_DB, RowStager, TransStager, MODE>(as, bs, 0, (p.K + XK - 1) / XK, p.M - m0, p.N - n0,
-                                                     p.c + t.batch * p.sc + (long long)m0 * p.ldc + n0, p.ldc, lds_x3);
+                                                     p.c + t.batch * p.sc + (long long)m0 * p.ldc + n0, p.ldc, lds_x3, 0,
+                                                     (MODE == 3 && p.bias) ? p.bias + m0 : nullptr, p.act);
     }
 }
 }  // namespace
 
-extern "C" int mk_conv1x1_x3(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K,
-                             long long N, int batch, long long sa, long long sb, long long sc, int mode, void* stream) {
+static int conv_x3_launch(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K,
+                          long long N, int batch, long long sa, long long sb, long long sc, int mode, const float* bias, int act,
+                          void* stream) {
     MK_REQUIRE(a && b && c, "null pointer");
     MK_REQUIRE(M > 0 && K > 0 && N > 0 && batch > 0, "bad sizes");
-    MK_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (store), 1 (accumulate) or 2 (weight gradient)");
+    MK_REQUIRE(mode >= 0 && mode <= 3, "mode must be 0 (store), 1 (accumulate), 2 (weight gradient) or 3 (store with bias / GELU)");
     MK_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 15) == 0, "operands must be 16-byte aligned");
     ConvX3Params p;
     p.a = a; p.b = b; p.c = c;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sa = sa; p.sb = sb; p.sc = sc;
     p.M = M; p.K = K;
+    p.bias = bias; p.act = act;
     MK_REQUIRE(N < 2147483647LL, "N too large");
     p.N = (int)N;
     p.tiles_m = mk::ceil_div(M, XM);
@@ -926,7 +941,23 @@ extern "C" int mk_conv1x1_x3(const float* a, long long lda, const float* b, long
     hipStream_t st = (hipStream_t)stream;
     if (mode == 0) hipLaunchKernelGGL(conv_x3_kernel<0>, grid, blk, X3_LDS, st, p);
     else if (mode == 1) hipLaunchKernelGGL(conv_x3_kernel<1>, grid, blk, X3_LDS, st, p);
-    else hipLaunchKernelGGL(conv_x3_kernel<2>, grid, blk, X3_LDS, st, p);
+    else if (mode == 2) hipLaunchKernelGGL(conv_x3_kernel<2>, grid, blk, X3_LDS, st, p);
+    else hipLaunchKernelGGL(conv_x3_kernel<3>, grid, blk, X3_LDS, st, p);
     MK_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int mk_conv1x1_x3(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M, int K,
+                             long long N, int batch, long long sa, long long sb, long long sc, int mode, void* stream) {
+    MK_REQUIRE(mode >= 0 && mode <= 2, "mode must be 0 (store), 1 (accumulate) or 2 (weight gradient)");
+    return conv_x3_launch(a, lda, b, ldb, c, ldc, M, K, N, batch, sa, sb, sc, mode, nullptr, 0, stream);
+}
+
+// C[b] = act(A B[b] + bias): the fp32 convolution with its bias add and (act = 1) exact GELU in the epilogue -- what
+// `nn.Conv2d(cin, cout, 1, bias=True)` + `nn.GELU()` (layers.py:95-99, 158-206) compute, in one pass over the output.
+extern "C" int mk_conv1x1_x3_bias_act(const float* a, long long lda, const float* b, long long ldb, float* c, long long ldc, int M,
+                                      int K, long long N, int batch, long long sb, long long sc, const float* bias, int act,
+                                      void* stream) {
+    MK_REQUIRE(act == 0 || act == 1, "act must be 0 (none) or 1 (exact GELU)");
+    return conv_x3_launch(a, lda, b, ldb, c, ldc, M, K, N, batch, 0, sb, sc, 3, bias, act, stream);
 }

@@ -381,7 +381,11 @@ class Conv1x1(nn.Conv2d):
         if x.dim() != 4 or not x.is_contiguous() or not x.is_cuda:
             y = F.conv2d(x, self.weight, self.bias if add_bias else None)
             return y if addend is None else y + addend
-        # fp32 fields (no autocast): torch mm / bmm on the [C, H*W] row-major view, HIP wgrad kernel for bf16 only
+        if addend is None and add_bias and self.bias is not None:
+            y = _x3_inference_conv(self, x, False)        # fp32 inference: the bias add rides in the GEMM's epilogue
+            if y is not None:
+                return y
+        # fp32 fields (no autocast): the bf16x3 engine (`_X3Conv`); torch mm / bmm only as the MK_CONV_FP32=torch A/B path
         if torch.is_autocast_enabled():
             x3 = x.view(B, x.shape[1], H * W).to(torch.get_autocast_dtype('cuda'))
         else:
@@ -397,6 +401,22 @@ class Conv1x1(nn.Conv2d):
         if self.bias is not None and add_bias:
             y = y + self.bias.to(y.dtype).view(1, -1, 1)
         return y.view(B, self.out_channels, H, W)
+
+
+def _x3_inference_conv(m, x, gelu):
+    """fp32 field, grad mode off: ``act(conv(x) + bias)`` as ONE launch of the bf16x3 engine (bias and exact GELU in the epilogue,
+    ``mk_conv1x1_x3_bias_act``), or None where that path does not apply."""
+    from . import ops
+    if torch.is_grad_enabled() or x.dim() != 4 or not x.is_cuda or not x.is_contiguous() or x.dtype != torch.float32:
+        return None
+    if torch.is_autocast_enabled() or os.environ.get("MK_CONV_FP32", "x3") != "x3":
+        return None
+    B, H, W = x.shape[0], x.shape[2], x.shape[3]
+    x3 = x.view(B, x.shape[1], H * W)
+    if not ops.conv1x1_x3_supported(x3) or (H * W) % 4 != 0 or m.weight.dtype != torch.float32:
+        return None
+    y = ops.conv1x1_x3(m.weight2d().detach(), x3, bias=None if m.bias is None else m.bias.detach(), gelu=gelu)
+    return y.view(B, m.out_channels, H, W)
 
 
 def _is_exact_gelu(m):
@@ -459,6 +479,11 @@ def run_pointwise_chain(mods, x, skip_last_bias=False, want_row_sums=False):
             i += 1
             continue
         if isinstance(m, Conv1x1) and i + 1 < len(mods) and _is_exact_gelu(mods[i + 1]) and x.is_cuda:
+            y = _x3_inference_conv(m, x, True)            # fp32 inference: conv + bias + GELU in one launch
+            if y is not None:
+                x = y
+                i += 2
+                continue
             y = m(x, add_bias=False)
             if ops.pointwise_supported(y):
                 x = ops.bias_gelu(y, m.bias)

@@ -382,13 +382,23 @@ def conv1x1_x3_supported(x3):
     return x3.is_cuda and x3.dtype == torch.float32 and x3.dim() == 3 and x3.is_contiguous() and x3.shape[2] % 2 == 0
 
 
-def conv1x1_x3(w, x3, out=None):
-    """y[b] = w @ x3[b] (``out`` given: ``out[b] += w @ x3[b]`` in place): w fp32 ``[M, K]``, x3 fp32 ``[B, K, P]`` (``mk_conv1x1_x3``)."""
+def conv1x1_x3(w, x3, out=None, bias=None, gelu=False):
+    """y[b] = w @ x3[b] (``out`` given: ``out[b] += w @ x3[b]`` in place): w fp32 ``[M, K]``, x3 fp32 ``[B, K, P]`` (``mk_conv1x1_x3``).
+    ``bias`` / ``gelu`` (not with ``out``): ``y = act(w @ x3 + bias)`` in the kernel's epilogue (``mk_conv1x1_x3_bias_act``)."""
     _need_cuda(w, x3)
     assert w.dtype == torch.float32 and w.dim() == 2 and conv1x1_x3_supported(x3) and w.shape[1] == x3.shape[1]
     b, k, p = x3.shape
     m = w.shape[0]
     a = _pad4(w)
+    if bias is not None or gelu:
+        assert out is None
+        bf = None if bias is None else bias.detach().float().contiguous()
+        assert bf is None or bf.numel() == m
+        y = torch.empty(b, m, p, dtype=torch.float32, device=x3.device)
+        _lib.check(_lib.load().mk_conv1x1_x3_bias_act(a.data_ptr(), a.stride(0), x3.data_ptr(), p, y.data_ptr(), p, m, k, p, b, k * p,
+                                                      m * p, None if bf is None else bf.data_ptr(), int(bool(gelu)), _stream()),
+                   "mk_conv1x1_x3_bias_act")
+        return y
     if out is not None:
         assert out.dtype == torch.float32 and out.is_contiguous() and tuple(out.shape) == (b, m, p)
     y = out if out is not None else torch.empty(b, m, p, dtype=torch.float32, device=x3.device)

@@ -516,6 +516,25 @@ def test_irfft_row_statistics(dev, nlat, nlon, mmax, B, C, cpp, dtype):
     assert torch.equal(xf2.grad, xf3.grad)
 
 
+@pytest.mark.parametrize("M,K,P,B,bias,gelu", [(384, 384, 1000, 2, True, True), (768, 73, 520, 1, True, False), (73, 384, 264, 3, False, True),
+                                                 (130, 200, 136, 1, True, True)])
+def test_conv1x1_x3_bias_gelu_epilogue(dev, M, K, P, B, bias, gelu):
+    """mk_conv1x1_x3_bias_act: the fp32 convolution with the bias add and the exact GELU in its epilogue (the inference path of
+    `nn.Conv2d(.., 1)` + `nn.GELU()`, layers.py:95-99, 158-206) against the float64 composition."""
+    from makani_amd import ops
+    g = torch.Generator().manual_seed(12)
+    w = (torch.randn(M, K, generator=g) / K ** 0.5).to(dev)
+    x = torch.randn(B, K, P, generator=g).to(dev)
+    b = torch.randn(M, generator=g).to(dev) if bias else None
+    y = ops.conv1x1_x3(w, x, bias=b, gelu=gelu)
+    want = torch.einsum("mk,bkp->bmp", w.double(), x.double())
+    if bias:
+        want = want + b.double().view(1, -1, 1)
+    if gelu:
+        want = torch.nn.functional.gelu(want)
+    assert rel(y.cpu().numpy(), want.cpu().numpy()) < 2e-6
+
+
 def test_adam_step_matches_torch(dev):
     """mk_adam_step (one streaming pass, makani_amd/optim.py) against torch.optim.Adam over three steps, on a real
     tensor, a complex one and a permuted-contiguous one (the dhconv weight layout), with weight decay."""

@@ -533,3 +533,22 @@ def test_capture_after_eager_steps_on_the_default_stream(dev):
     assert torch.isfinite(static_loss).all()
     for n, p in net.named_parameters():
         assert p.grad is not None and rel(p.grad, ref[n], floor=1e-6) < 1e-3, n
+
+
+def test_fp32_inference_path_matches_training_forward(dev):
+    """Grad mode off, fp32: the convolutions carry their bias / GELU in the GEMM epilogue (`mk_conv1x1_x3_bias_act`) and the bf16 MLP
+    node keeps no pre-activation -- the output must be the training-mode forward's (fp32 rounding aside)."""
+    from makani_amd.sfnonet import SphericalFourierNeuralOperatorNet
+    torch.manual_seed(13)
+    kw = dict(inp_shape=(32, 64), out_shape=(32, 64), scale_factor=2, inp_chans=4, out_chans=3, embed_dim=16, num_layers=2, bias=False)
+    net = SphericalFourierNeuralOperatorNet(**kw).to(dev)
+    x = torch.randn(2, 4, 32, 64, device=dev)
+    y_train = net(x).detach()
+    with torch.no_grad():
+        y_eval = net(x)
+    assert rel(y_eval, y_train) < 2e-6
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yb_train = net(x).detach()
+        with torch.no_grad():
+            yb_eval = net(x)
+    assert torch.equal(yb_eval, yb_train)
