@@ -445,8 +445,9 @@ class EngineArena:
         lib = _lib.load()
         rows, self.slots, off, goff = [], {}, 0, 0
         self.gslots = {}
-        for w in self.weights:
-            for transpose in (False, True):
+        self.n_fwd = self.total_fwd = 0
+        for transpose in (False, True):            # the forward images first: inference (grad mode off) packs only those
+            for w in self.weights:
                 m, k = (w.shape[1], w.shape[0]) if transpose else (w.shape[0], w.shape[1])
                 nbytes = lib.mk_pce_image_bytes(m, k)
                 if nbytes <= 0:
@@ -457,6 +458,9 @@ class EngineArena:
                              lay[2], off])
                 self.slots[self._key(w, transpose)] = (off * 2, nbytes)
                 off += nbytes // 2
+            if not transpose:
+                self.n_fwd, self.total_fwd = len(rows), off
+        for w in self.weights:
             self.gslots[self._key(w, False)] = (goff, w.shape[0], w.shape[1])
             goff += (w.numel() + 3) // 4 * 4           # 16-byte aligned buffers
         self.total, self.gtotal = off, goff
@@ -472,13 +476,17 @@ class EngineArena:
         return (w.data_ptr(), tuple(w.shape), w.stride(0), w.dtype, bool(transpose))
 
     def refresh(self, with_grad_buffers):
-        if self.n:
-            _lib.check(_lib.load().mk_pce_pack_batch(self.desc.data_ptr(), self.n, self.images.data_ptr(), self.total, _stream()),
+        n, total = (self.n, self.total) if with_grad_buffers else (self.n_fwd, self.total_fwd)
+        self._packed_all = bool(with_grad_buffers)
+        if n:
+            _lib.check(_lib.load().mk_pce_pack_batch(self.desc.data_ptr(), n, self.images.data_ptr(), total, _stream()),
                        "mk_pce_pack_batch")
         # a fresh buffer per step: the views handed out become the parameters' gradients and live as long as those do
         self.gbuf = torch.zeros(self.gtotal, dtype=torch.float32, device=self.images.device) if (with_grad_buffers and self.gtotal) else None
 
     def image(self, w, transpose):
+        if transpose and not self._packed_all:       # grad mode was off at scope entry: the transposed images are stale
+            return None
         slot = self.slots.get(self._key(w, transpose))
         return None if slot is None else self.images[slot[0]:slot[0] + slot[1]]
 
